@@ -1,0 +1,138 @@
+/*
+ * gridhip.h — C ABI of libgridhip.so: MI355X (gfx950 / CDNA4) native convolutional
+ * w-projection gridder / degridder.
+ *
+ * This is the drop-in boundary for the gridding hot path of
+ * sakehl/SKA-SDP-Accelerate-gridding.  Each entry point replaces the *body* of one
+ * Accelerate function of /root/reference/src/Gridding.hs (cited per function); the Haskell
+ * signatures stay, the `run` over the array program becomes a `foreign import ccall` into
+ * this library (binding shown in INTEGRATION.md).
+ *
+ * Conventions (all follow the reference's own FFI style, hdf5/hdf5.cc:59-186 and
+ * src/Hdf5.hs:30-67: extern "C", plain pointers + integers, caller allocates outputs):
+ *   F = double, Int = int64_t, Antenna = int64_t            (src/Types.hs:7-16)
+ *   Complex Double arrays = interleaved (re,im) doubles     (src/Hdf5.hs:113-137, hdf5/hdf5.cc:14-17)
+ *   Vector (F,F,F) = separate u / v / w pointers; `uv_stride` is the element stride between
+ *       consecutive visibilities (1 for struct-of-arrays as Accelerate stores tuples, 3 when u
+ *       and v point into the (n,3) row-major /vis/uvw matrix, src/ImageDataset.hs:94-97)
+ *   grids are row-major [y][x] (y <-> v axis), H rows x Wd columns (src/Gridding.hs:106-109)
+ *   gcf   = [W][Q][Q][gh][gw] complex, index order (wbin, yf, xf, i, j) (src/Gridding.hs:243)
+ *   grids are ACCUMULATED INTO (permute (+) a ..., src/Gridding.hs:99,197,244), never overwritten
+ *   the library never retains or frees a caller pointer past the call
+ *
+ * Every function returns GRIDHIP_OK (0) or a negative GRIDHIP_E* code; the message for the
+ * last failure on a context is available from gridhip_last_error().  (The reference's FFI
+ * reports nothing; this is the one deliberate departure)
+ *
+ * Two flavours per operation:
+ *   gridhip_<op>      host pointers, synchronous — the drop-in form;
+ *   gridhip_<op>_dev  device pointers, asynchronous on the context's stream — what the
+ *                     benchmark and multi-GPU drivers use so that H2D is outside the timing.
+ * A context is bound to one device and one stream and is not thread-safe.
+ */
+#ifndef GRIDHIP_H
+#define GRIDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRIDHIP_VERSION 100 /* 0.1.0 */
+
+#define GRIDHIP_OK 0
+#define GRIDHIP_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
+#define GRIDHIP_ENOMEM (-2)       /* device or host allocation failed */
+#define GRIDHIP_EHIP (-3)         /* HIP runtime / library error, see gridhip_last_error */
+#define GRIDHIP_ENODEV (-4)       /* no usable gfx950 device */
+#define GRIDHIP_EUNSUPPORTED (-5) /* shape outside what the kernels support */
+
+typedef struct gridhip_ctx gridhip_ctx;
+
+/* ---- context --------------------------------------------------------------------------- */
+int gridhip_version(void);
+const char *gridhip_strerror(int code);
+int gridhip_device_count(int *count);
+/* Create a context on HIP device `device` with its own non-blocking stream. */
+int gridhip_create(int device, gridhip_ctx **ctx);
+int gridhip_destroy(gridhip_ctx *ctx);
+const char *gridhip_last_error(const gridhip_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
+ * context's own stream. */
+int gridhip_set_stream(gridhip_ctx *ctx, void *hip_stream);
+void *gridhip_get_stream(gridhip_ctx *ctx);
+int gridhip_synchronize(gridhip_ctx *ctx);
+/* Tuning knobs (all have defaults chosen per shape):
+ *   "tile"      grid-tile side T in cells (power of two, 8..128; 0 = auto)
+ *   "block"     threads per work-group of the tile kernels (multiple of 64, <=1024; 0 = auto)
+ *   "chunk"     max visibilities per work item (0 = auto)
+ *   "wgroups"   number of w-plane groups work items are split into for XCD/L2 locality (1..8; 0 = auto)
+ *   "variant"   0 = LDS-tile accumulate (default), 1 = direct global-atomic scatter (baseline)
+ *   "sort"      1 = order each bin by kernel slice so consecutive visibilities reuse taps (0 = off)
+ */
+int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value);
+int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value);
+/* Visibilities skipped by the last gridding call because `wbin` was outside [0,W) (the
+ * reference would read the kernel out of range).  Synchronises the stream. */
+int gridhip_last_dropped(gridhip_ctx *ctx, int64_t *dropped);
+
+/* ---- gridders: host pointers (drop-in) -------------------------------------------------- */
+
+/* grid  — src/Gridding.hs:95-112.   G[N/2+floor(.5+N*v), N/2+floor(.5+N*u)] += vis
+ * (N = H as in the reference, :101-103; cells outside the grid are dropped). */
+int gridhip_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                 const double *u, const double *v, int64_t uv_stride, const double *vis);
+
+/* convgrid — src/Gridding.hs:153-197.  gcf is [Q][Q][gh][gw]. */
+int gridhip_convgrid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                     int64_t Q, int64_t gh, int64_t gw, const double *gcf, const double *u,
+                     const double *v, int64_t uv_stride, const double *vis);
+
+/* convgrid2 — src/Gridding.hs:199-244 (the w-projection kernel).  gcf is [W][Q][Q][gh][gw]. */
+int gridhip_convgrid2(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                      int64_t W, int64_t Q, int64_t gh, int64_t gw, const double *gcf,
+                      const double *u, const double *v, int64_t uv_stride,
+                      const int64_t *wbin, const double *vis);
+
+/* degrid2 — the gather with convgrid2's coordinates (north_star "degrid"; absent from the
+ * reference, defined in SURVEY.md §8a): vis_out[k] = sum_ij gcf[wbin,yf,xf,i,j]*G[y0+i,x0+j]. */
+int gridhip_degrid2(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *grid, int64_t n,
+                    int64_t W, int64_t Q, int64_t gh, int64_t gw, const double *gcf,
+                    const double *u, const double *v, int64_t uv_stride,
+                    const int64_t *wbin, double *vis_out);
+
+/* ---- gridders: device pointers, asynchronous on the context's stream --------------------- */
+int gridhip_grid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                     const double *u, const double *v, int64_t uv_stride, const double *vis);
+int gridhip_convgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                         int64_t Q, int64_t gh, int64_t gw, const double *gcf,
+                         const double *u, const double *v, int64_t uv_stride,
+                         const double *vis);
+int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                          int64_t W, int64_t Q, int64_t gh, int64_t gw, const double *gcf,
+                          const double *u, const double *v, int64_t uv_stride,
+                          const int64_t *wbin, const double *vis);
+int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *grid,
+                        int64_t n, int64_t W, int64_t Q, int64_t gh, int64_t gw,
+                        const double *gcf, const double *u, const double *v,
+                        int64_t uv_stride, const int64_t *wbin, double *vis_out);
+
+/* ---- device memory helpers (so a non-HIP host language can stage buffers) ----------------- */
+int gridhip_malloc(gridhip_ctx *ctx, void **dptr, int64_t bytes);
+int gridhip_free(gridhip_ctx *ctx, void *dptr);
+int gridhip_memcpy_h2d(gridhip_ctx *ctx, void *dst, const void *src, int64_t bytes);
+int gridhip_memcpy_d2h(gridhip_ctx *ctx, void *dst, const void *src, int64_t bytes);
+int gridhip_memset(gridhip_ctx *ctx, void *dptr, int value, int64_t bytes);
+
+/* ---- timing of the last device call (HIP events on the context's stream) ------------------
+ * ms_total covers binning pre-pass + tile kernel; ms_kernel the dominant kernel only.
+ * Synchronises on the recorded events. */
+int gridhip_last_timing(gridhip_ctx *ctx, double *ms_total, double *ms_prepass,
+                        double *ms_kernel);
+int gridhip_enable_timing(gridhip_ctx *ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIDHIP_H */

@@ -1,0 +1,224 @@
+// C-ABI entry points of the gridders (include/gridhip.h): argument checks, the device-pointer
+// forms that enqueue the kernels, and the host-pointer drop-in forms that stage through HBM.
+#include <vector>
+
+#include "common.h"
+
+using namespace gridhip;
+
+namespace {
+
+int check_common(gridhip_ctx *ctx, int64_t H, int64_t Wd, const void *grid, int64_t n, const void *u,
+                 const void *v, int64_t uv_stride)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    if (H <= 0 || Wd <= 0 || n < 0 || uv_stride < 1)
+        return fail(ctx, GRIDHIP_EINVAL, "bad size (H=%lld Wd=%lld n=%lld uv_stride=%lld)", (long long)H,
+                    (long long)Wd, (long long)n, (long long)uv_stride);
+    if (!grid || (n > 0 && (!u || !v))) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
+    if (n > (int64_t)0x7fffff00) return fail(ctx, GRIDHIP_EUNSUPPORTED, "n must be < 2^31 per call");
+    return GRIDHIP_OK;
+}
+
+void mark(gridhip_ctx *ctx, int i)
+{
+    if (ctx->timing) (void)hipEventRecord(ctx->ev[i], ctx->stream);
+}
+
+// bump allocator over the staging workspace
+struct Stage {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t count)
+    {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+size_t aligned(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+int gridhip_grid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, const double *u,
+                     const double *v, int64_t uv_stride, const double *vis)
+{
+    GH_CHECK(check_common(ctx, H, Wd, grid, n, u, v, uv_stride));
+    if (n > 0 && !vis) return fail(ctx, GRIDHIP_EINVAL, "null vis");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    mark(ctx, 0);
+    mark(ctx, 1);
+    GH_CHECK(launch_simple_grid(ctx, H, Wd, grid, n, u, v, uv_stride, vis));
+    mark(ctx, 2);
+    ctx->ev_valid = ctx->timing;
+    return GRIDHIP_OK;
+}
+
+int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W, int64_t Q,
+                          int64_t gh, int64_t gw, const double *gcf, const double *u, const double *v,
+                          int64_t uv_stride, const int64_t *wbin, const double *vis)
+{
+    GH_CHECK(check_common(ctx, H, Wd, grid, n, u, v, uv_stride));
+    if (!gcf || (n > 0 && !vis)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
+    if (W <= 0 || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel shape");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->opt.variant == 1 || gw > 64) {
+        mark(ctx, 0);
+        mark(ctx, 1);
+        GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
+        mark(ctx, 2);
+        ctx->ev_valid = ctx->timing;
+        return GRIDHIP_OK;
+    }
+    Geom g;
+    int block;
+    size_t lds;
+    GH_CHECK(make_geom(ctx, H, Wd, W, Q, gh, gw, n, &g, &block, &lds));
+    // scratch is sized before the timed region begins
+    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
+    mark(ctx, 0);
+    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin, vis));
+    mark(ctx, 1);
+    if (n > 0) GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, grid));
+    mark(ctx, 2);
+    ctx->ev_valid = ctx->timing;
+    return GRIDHIP_OK;
+}
+
+int gridhip_convgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t Q, int64_t gh,
+                         int64_t gw, const double *gcf, const double *u, const double *v, int64_t uv_stride,
+                         const double *vis)
+{
+    // convgrid is convgrid2 with a single plane and wbin = 0 (src/Gridding.hs:196 vs :243)
+    return gridhip_convgrid2_dev(ctx, H, Wd, grid, n, 1, Q, gh, gw, gcf, u, v, uv_stride, nullptr, vis);
+}
+
+int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *grid, int64_t n, int64_t W,
+                        int64_t Q, int64_t gh, int64_t gw, const double *gcf, const double *u, const double *v,
+                        int64_t uv_stride, const int64_t *wbin, double *vis_out)
+{
+    GH_CHECK(check_common(ctx, H, Wd, grid, n, u, v, uv_stride));
+    if (!gcf || (n > 0 && !vis_out)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
+    if (W <= 0 || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel shape");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    Geom g;
+    int block;
+    size_t lds;
+    GH_CHECK(make_geom(ctx, H, Wd, W, Q, gh, gw, n, &g, &block, &lds));
+    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
+    mark(ctx, 0);
+    // visibilities with no tap inside the grid (or an out-of-range wbin) predict 0
+    if (n > 0) GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)n * 16, ctx->stream));
+    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin, nullptr));
+    mark(ctx, 1);
+    if (n > 0) GH_CHECK(launch_tile_degrid(ctx, g, block, lds, n, gcf, grid, vis_out));
+    mark(ctx, 2);
+    ctx->ev_valid = ctx->timing;
+    return GRIDHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer forms
+
+static int stage_uv(gridhip_ctx *ctx, Stage &st, int64_t n, int64_t stride, const double *u, const double *v,
+                    double **du, double **dv)
+{
+    const size_t span = n > 0 ? (size_t)(n - 1) * stride + 1 : 0;
+    *du = st.take<double>(span ? span : 1);
+    *dv = st.take<double>(span ? span : 1);
+    if (span) {
+        GH_CHECK_HIP(ctx, hipMemcpyAsync(*du, u, span * 8, hipMemcpyHostToDevice, ctx->stream));
+        GH_CHECK_HIP(ctx, hipMemcpyAsync(*dv, v, span * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return GRIDHIP_OK;
+}
+
+int gridhip_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, const double *u,
+                 const double *v, int64_t uv_stride, const double *vis)
+{
+    GH_CHECK(check_common(ctx, H, Wd, grid, n, u, v, uv_stride));
+    if (n > 0 && !vis) return fail(ctx, GRIDHIP_EINVAL, "null vis");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)H * Wd, span = n > 0 ? (size_t)(n - 1) * uv_stride + 1 : 1;
+    GH_CHECK(ws_reserve(ctx, ctx->stage, aligned(cells * 16) + 2 * aligned(span * 8) + aligned((size_t)n * 16 + 16)));
+    Stage st{(char *)ctx->stage.ptr};
+    double *dg = st.take<double>(cells * 2), *du, *dv;
+    GH_CHECK(stage_uv(ctx, st, n, uv_stride, u, v, &du, &dv));
+    double *dvis = st.take<double>((size_t)n * 2 + 2);
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(dg, grid, cells * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (n) GH_CHECK_HIP(ctx, hipMemcpyAsync(dvis, vis, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    GH_CHECK(gridhip_grid_dev(ctx, H, Wd, dg, n, du, dv, uv_stride, dvis));
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(grid, dg, cells * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GRIDHIP_OK;
+}
+
+int gridhip_convgrid2(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W, int64_t Q,
+                      int64_t gh, int64_t gw, const double *gcf, const double *u, const double *v,
+                      int64_t uv_stride, const int64_t *wbin, const double *vis)
+{
+    GH_CHECK(check_common(ctx, H, Wd, grid, n, u, v, uv_stride));
+    if (!gcf || (n > 0 && !vis)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
+    if (W <= 0 || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel shape");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)H * Wd, span = n > 0 ? (size_t)(n - 1) * uv_stride + 1 : 1;
+    const size_t kel = (size_t)W * Q * Q * gh * gw;
+    GH_CHECK(ws_reserve(ctx, ctx->stage, aligned(cells * 16) + 2 * aligned(span * 8) + aligned((size_t)n * 16 + 16) +
+                                             aligned((size_t)n * 8 + 8) + aligned(kel * 16)));
+    Stage st{(char *)ctx->stage.ptr};
+    double *dg = st.take<double>(cells * 2), *du, *dv;
+    GH_CHECK(stage_uv(ctx, st, n, uv_stride, u, v, &du, &dv));
+    double *dvis = st.take<double>((size_t)n * 2 + 2);
+    int64_t *dwb = st.take<int64_t>((size_t)n + 1);
+    double *dk = st.take<double>(kel * 2);
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(dg, grid, cells * 16, hipMemcpyHostToDevice, ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(dk, gcf, kel * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (n) GH_CHECK_HIP(ctx, hipMemcpyAsync(dvis, vis, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (n && wbin) GH_CHECK_HIP(ctx, hipMemcpyAsync(dwb, wbin, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    GH_CHECK(gridhip_convgrid2_dev(ctx, H, Wd, dg, n, W, Q, gh, gw, dk, du, dv, uv_stride, wbin ? dwb : nullptr, dvis));
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(grid, dg, cells * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GRIDHIP_OK;
+}
+
+int gridhip_convgrid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t Q, int64_t gh,
+                     int64_t gw, const double *gcf, const double *u, const double *v, int64_t uv_stride,
+                     const double *vis)
+{
+    return gridhip_convgrid2(ctx, H, Wd, grid, n, 1, Q, gh, gw, gcf, u, v, uv_stride, nullptr, vis);
+}
+
+int gridhip_degrid2(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *grid, int64_t n, int64_t W, int64_t Q,
+                    int64_t gh, int64_t gw, const double *gcf, const double *u, const double *v, int64_t uv_stride,
+                    const int64_t *wbin, double *vis_out)
+{
+    GH_CHECK(check_common(ctx, H, Wd, grid, n, u, v, uv_stride));
+    if (!gcf || (n > 0 && !vis_out)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
+    if (W <= 0 || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel shape");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)H * Wd, span = n > 0 ? (size_t)(n - 1) * uv_stride + 1 : 1;
+    const size_t kel = (size_t)W * Q * Q * gh * gw;
+    GH_CHECK(ws_reserve(ctx, ctx->stage, aligned(cells * 16) + 2 * aligned(span * 8) + aligned((size_t)n * 16 + 16) +
+                                             aligned((size_t)n * 8 + 8) + aligned(kel * 16)));
+    Stage st{(char *)ctx->stage.ptr};
+    double *dg = st.take<double>(cells * 2), *du, *dv;
+    GH_CHECK(stage_uv(ctx, st, n, uv_stride, u, v, &du, &dv));
+    double *dvis = st.take<double>((size_t)n * 2 + 2);
+    int64_t *dwb = st.take<int64_t>((size_t)n + 1);
+    double *dk = st.take<double>(kel * 2);
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(dg, grid, cells * 16, hipMemcpyHostToDevice, ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(dk, gcf, kel * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (n && wbin) GH_CHECK_HIP(ctx, hipMemcpyAsync(dwb, wbin, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    GH_CHECK(gridhip_degrid2_dev(ctx, H, Wd, dg, n, W, Q, gh, gw, dk, du, dv, uv_stride, wbin ? dwb : nullptr, dvis));
+    if (n) GH_CHECK_HIP(ctx, hipMemcpyAsync(vis_out, dvis, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GRIDHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+// Binning pre-pass: turn the caller's (u, v, wbin, vis) stream into tile-ordered VisRec
+// records so that the tile kernels can accumulate a whole grid tile in LDS.
+//
+//   bin_count   : histogram of visibilities per bin (bin = w-group x grid tile), LDS-privatised
+//   bin_scan    : exclusive scans -> bin_start[], per-group work_start[] (chunks of <=chunk vis)
+//   bin_scatter : second sweep writes each visibility's VisRec into its bin's slot range
+//
+// Coordinates follow frac_coords / convgrid2 of src/Gridding.hs:126-151,212-218: the footprint
+// origin is (x - gw/2, y - gh/2); a visibility none of whose taps can land inside the grid is
+// dropped here (fixoutofbounds would drop every one of its taps, :883-891).
+#include "common.h"
+
+namespace gridhip {
+
+struct BinOut {
+    int32_t bin;  // -1: no tap in the grid, -2: wbin outside [0,W)
+    int32_t lxy, kslice;
+};
+
+__device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, int64_t wb)
+{
+    BinOut o;
+    int64_t x, y;
+    int32_t xf, yf;
+    frac_coord_dev(g.Wd, g.Q, pu, &x, &xf);
+    frac_coord_dev(g.H, g.Q, pv, &y, &yf);
+    const int64_t x0 = x - g.gw / 2, y0 = y - g.gh / 2;
+    // NaN coordinates compare false everywhere below and are dropped by the first test
+    if (!(pu == pu) || !(pv == pv) || x0 <= -(int64_t)g.gw || x0 >= g.Wd || y0 <= -(int64_t)g.gh ||
+        y0 >= g.H) {
+        o.bin = -1;
+        o.lxy = 0;
+        o.kslice = 0;
+        return o;
+    }
+    if (wb < 0 || wb >= g.W) {
+        o.bin = -2;
+        o.lxy = 0;
+        o.kslice = 0;
+        return o;
+    }
+    const int32_t X = (int32_t)x0 + g.offx, Y = (int32_t)y0 + g.offy;
+    const int32_t tx = X >> g.tshift, ty = Y >> g.tshift;  // X, Y >= 0 by construction of offx/offy
+    const int32_t lx = X & (g.T - 1), ly = Y & (g.T - 1);
+    const int32_t grp = (int32_t)((wb * g.ngroups) / g.W);
+    o.bin = grp * g.ntiles + ty * g.ntx + tx;
+    o.lxy = (ly << 16) | lx;
+    o.kslice = ((int32_t)wb * g.Q + yf) * g.Q + xf;
+    return o;
+}
+
+// Each block owns one contiguous slice of the stream (the same slice in both sweeps).
+__device__ __forceinline__ void block_range(int64_t n, int64_t *lo, int64_t *hi)
+{
+    int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + 255) & ~(int64_t)255;
+    *lo = (int64_t)blockIdx.x * per;
+    *hi = *lo + per < n ? *lo + per : n;
+    if (*lo > n) *lo = n;
+}
+
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, const double *__restrict__ u,
+                                                         const double *__restrict__ v, int64_t stride,
+                                                         const int64_t *__restrict__ wbin,
+                                                         int32_t *__restrict__ bin_count,
+                                                         int32_t *__restrict__ scalars)
+{
+    extern __shared__ int32_t hist[];
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+    }
+    int64_t lo, hi;
+    block_range(n, &lo, &hi);
+    int dropped = 0;
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0);
+        if (b.bin >= 0) {
+            if (LDS_HIST)
+                atomicAdd(&hist[b.bin], 1);
+            else
+                atomicAdd(&bin_count[b.bin], 1);
+        } else if (b.bin == -2)
+            ++dropped;
+    }
+    if (dropped) atomicAdd(&scalars[0], dropped);
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) {
+            int c = hist[i];
+            if (c) atomicAdd(&bin_count[i], c);
+        }
+    }
+}
+
+// Single work-group scan (nbins is at most a few hundred thousand).
+// bin_start  : exclusive scan of bin_count over all bins (group-major order)
+// work_start : per group, exclusive scan of ceil(count/chunk) over that group's tiles
+__global__ void __launch_bounds__(1024) bin_scan_kernel(Geom g, const int32_t *__restrict__ bin_count,
+                                                        int32_t *__restrict__ bin_start,
+                                                        int32_t *__restrict__ work_start,
+                                                        int32_t *__restrict__ cursor)
+{
+    __shared__ int32_t part[1024];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // ---- bin_start over all bins
+    {
+        const int per = (g.nbins + nt - 1) / nt;
+        const int lo = tid * per, hi = min(lo + per, g.nbins);
+        int s = 0;
+        for (int i = lo; i < hi; ++i) s += bin_count[i];
+        part[tid] = s;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int i = 0; i < nt; ++i) {
+                int t = part[i];
+                part[i] = acc;
+                acc += t;
+            }
+            bin_start[g.nbins] = acc;
+        }
+        __syncthreads();
+        int acc = part[tid];
+        for (int i = lo; i < hi; ++i) {
+            bin_start[i] = acc;
+            cursor[i] = 0;
+            acc += bin_count[i];
+        }
+        __syncthreads();
+    }
+    // ---- work_start per group
+    for (int grp = 0; grp < g.ngroups; ++grp) {
+        const int32_t *cnt = bin_count + (size_t)grp * g.ntiles;
+        int32_t *ws = work_start + (size_t)grp * (g.ntiles + 1);
+        const int per = (g.ntiles + nt - 1) / nt;
+        const int lo = tid * per, hi = min(lo + per, g.ntiles);
+        int s = 0;
+        for (int i = lo; i < hi; ++i) s += (cnt[i] + g.chunk - 1) / g.chunk;
+        part[tid] = s;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int i = 0; i < nt; ++i) {
+                int t = part[i];
+                part[i] = acc;
+                acc += t;
+            }
+            ws[g.ntiles] = acc;
+            carry = acc;
+        }
+        __syncthreads();
+        int acc = part[tid];
+        for (int i = lo; i < hi; ++i) {
+            ws[i] = acc;
+            acc += (cnt[i] + g.chunk - 1) / g.chunk;
+        }
+        __syncthreads();
+    }
+    (void)carry;
+}
+
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
+                                                           const double *__restrict__ v, int64_t stride,
+                                                           const int64_t *__restrict__ wbin,
+                                                           const double *__restrict__ vis,
+                                                           const int32_t *__restrict__ bin_start,
+                                                           int32_t *__restrict__ cursor,
+                                                           VisRec *__restrict__ recs)
+{
+    extern __shared__ int32_t hist[];
+    int64_t lo, hi;
+    block_range(n, &lo, &hi);
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        // sweep 1: how many of this block's visibilities go to each bin
+        for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+            BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0);
+            if (b.bin >= 0) atomicAdd(&hist[b.bin], 1);
+        }
+        __syncthreads();
+        // reserve one contiguous slot range per (block, bin); hist[] becomes the next free slot
+        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) {
+            int c = hist[i];
+            if (c) hist[i] = bin_start[i] + atomicAdd(&cursor[i], c);
+        }
+        __syncthreads();
+    }
+    // sweep 2: write the records
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0);
+        if (b.bin < 0) continue;
+        int slot;
+        if (LDS_HIST)
+            slot = atomicAdd(&hist[b.bin], 1);
+        else
+            slot = bin_start[b.bin] + atomicAdd(&cursor[b.bin], 1);
+        VisRec r;
+        r.lxy = b.lxy;
+        r.kslice = b.kslice;
+        r.vr = vis ? vis[2 * k] : 0.0;
+        r.vi = vis ? vis[2 * k + 1] : 0.0;
+        r.orig = (int32_t)k;
+        r.pad = 0;
+        // 32-B record as two 16-B stores
+        int4 *dst = reinterpret_cast<int4 *>(recs + slot);
+        const int4 *src = reinterpret_cast<const int4 *>(&r);
+        dst[0] = src[0];
+        dst[1] = src[1];
+    }
+}
+
+int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
+               int64_t uv_stride, const int64_t *wbin, const double *vis)
+{
+    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
+    Tables t = tables_of(ctx, g);
+    GH_CHECK_HIP(ctx, hipMemsetAsync(t.bin_count, 0, (size_t)g.nbins * sizeof(int32_t), ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars, 0, 16 * sizeof(int32_t), ctx->stream));
+
+    const size_t hist_bytes = (size_t)g.nbins * sizeof(int32_t);
+    const bool lds_hist = hist_bytes <= (size_t)ctx->max_lds - 8192;
+    const int threads = 1024;
+    // one block per CU with an LDS histogram; more, smaller slices when counting in global memory
+    int blocks = lds_hist ? ctx->num_cu * (hist_bytes <= 64 * 1024 ? 2 : 1) : ctx->num_cu * 8;
+    int64_t need = (n + threads - 1) / threads;
+    if (need < 1) need = 1;
+    if (blocks > need) blocks = (int)need;
+
+    if (lds_hist) {
+        if (!(ctx->attr_mask & 1u)) {
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_scatter_kernel<true>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+            ctx->attr_mask |= 1u;
+        }
+        hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
+                           v, uv_stride, wbin, t.bin_count, t.scalars);
+    } else {
+        hipLaunchKernelGGL(bin_count_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
+                           uv_stride, wbin, t.bin_count, t.scalars);
+    }
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
+                       t.work_start, t.cursor);
+    if (lds_hist)
+        hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n,
+                           u, v, uv_stride, wbin, vis, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
+    else
+        hipLaunchKernelGGL(bin_scatter_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
+                           uv_stride, wbin, vis, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
+    GH_CHECK_HIP(ctx, hipGetLastError());
+    return GRIDHIP_OK;
+}
+
+}  // namespace gridhip

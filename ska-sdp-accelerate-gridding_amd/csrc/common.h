@@ -1,0 +1,148 @@
+// libgridhip internal declarations (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/gridhip.h"
+
+namespace gridhip {
+
+// One visibility after the binning pre-pass: everything the tile kernels need, 32 B so a
+// wave fetches it with one scalar load (s_load_dwordx8).
+struct __attribute__((aligned(32))) VisRec {
+    int32_t lxy;     // ly0 << 16 | lx0 : footprint origin relative to the tile's LDS region
+    int32_t kslice;  // (wbin*Q + yf)*Q + xf : which [gh][gw] kernel slice
+    double vr, vi;   // visibility
+    int32_t orig;    // index in the caller's arrays (degrid writes there)
+    int32_t pad;
+};
+static_assert(sizeof(VisRec) == 32, "VisRec must be 32 bytes");
+
+// Geometry of one gridding call, shared by host and device code.
+struct Geom {
+    int64_t H, Wd;        // grid rows, columns
+    int32_t W, Q, gh, gw; // kernel table dims
+    int32_t T;            // tile side (cells), power of two
+    int32_t tshift;       // log2(T)
+    int32_t offx, offy;   // coordinate offsets so tile indices start at 0
+    int32_t ntx, nty;     // tiles per row / column
+    int32_t ntiles;       // ntx*nty
+    int32_t ngroups;      // w-plane groups (bins = ngroups*ntiles)
+    int32_t nbins;
+    int32_t ldw;          // LDS row pitch in cells
+    int32_t lrows, lcols; // valid LDS region: T+gh-1 rows, T+gw-1 columns
+    int32_t rw;           // lanes per kernel row (power of two >= gw)
+    int32_t chunk;        // max visibilities per work item
+};
+
+struct Options {
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0;
+};
+
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace gridhip
+
+struct gridhip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    gridhip::Options opt;
+    // device scratch, grown on demand (never inside a timed/captured region after warm-up)
+    gridhip::Workspace recs;    // VisRec[n]
+    gridhip::Workspace keys;    // per-visibility sort keys / temporaries
+    gridhip::Workspace tables;  // bin_count / bin_start / work_start / cursors / scalars
+    gridhip::Workspace stage;   // staging for the host-pointer entry points
+    int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=last call's n; 16 ints
+    int num_cu = 256;
+    int max_lds = 160 * 1024;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    uint32_t attr_mask = 0;  // which kernels already had their dynamic-LDS limit raised
+};
+
+namespace gridhip {
+
+int fail(gridhip_ctx *ctx, int code, const char *fmt, ...);
+
+#define GH_CHECK_HIP(ctx, call)                                                          \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return gridhip::fail((ctx), e__ == hipErrorOutOfMemory ? GRIDHIP_ENOMEM      \
+                                                                   : GRIDHIP_EHIP,       \
+                                 "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                                 __FILE__, __LINE__);                                    \
+    } while (0)
+
+#define GH_CHECK(expr)              \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != GRIDHIP_OK)     \
+            return rc__;            \
+    } while (0)
+
+int ws_reserve(gridhip_ctx *ctx, Workspace &ws, size_t bytes);
+
+// geometry / option resolution (host)
+int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh,
+              int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes);
+
+// ---- device-side coordinate math ---------------------------------------------------------
+// frac_coord of src/Gridding.hs:126-140, bit-for-bit with the oracle: contraction is switched
+// off for this block so `halfn + p*n` stays a rounded multiply followed by a rounded add
+// (HIP's __dmul_rn/__dadd_rn are plain operators and would still be fused; checked in the ISA).
+__device__ __forceinline__ void frac_coord_dev(int64_t n, int32_t qpx, double p, int64_t *flx,
+                                               int32_t *fr)
+{
+#pragma clang fp contract(off)
+    const double halfnf = (double)(n / 2);
+    const double nf = (double)n;
+    const double qpxf = (double)qpx;
+    const double qpxfrac = 0.5 / qpxf;  // exact for power-of-two qpx, correctly rounded otherwise
+    const double pn = p * nf;
+    const double x = halfnf + pn;
+    const double fl = floor(x + qpxfrac);
+    const int64_t f = (int64_t)fl;
+    const double xd = x - (double)f;
+    const double d = xd * qpxf;
+    int32_t r = (int32_t)round(d);
+    r = r < 0 ? 0 : r;
+    r = r > qpx - 1 ? qpx - 1 : r;
+    *flx = f;
+    *fr = r;
+}
+
+// kernel launchers (each enqueues on ctx->stream)
+int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
+               int64_t uv_stride, const int64_t *wbin, const double *vis);
+int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int64_t n,
+                     const double *gcf, double *grid);
+int launch_tile_degrid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int64_t n,
+                       const double *gcf, const double *grid, double *vis_out);
+int launch_direct_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                       int64_t W, int64_t Q, int64_t gh, int64_t gw, const double *gcf,
+                       const double *u, const double *v, int64_t uv_stride,
+                       const int64_t *wbin, const double *vis);
+int launch_simple_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
+                       const double *u, const double *v, int64_t uv_stride, const double *vis);
+
+// layout of the `tables` workspace (all int32 unless noted); see bin.hip
+struct Tables {
+    int32_t *bin_count;   // [nbins]
+    int32_t *bin_start;   // [nbins+1] exclusive scan of bin_count
+    int32_t *work_start;  // [ngroups][ntiles+1] exclusive scan of chunks per bin, per group
+    int32_t *cursor;      // [nbins] scatter cursors
+    int32_t *scalars;     // = ctx->d_scalars
+};
+Tables tables_of(gridhip_ctx *ctx, const Geom &g);
+size_t tables_bytes(const Geom &g);
+
+}  // namespace gridhip

@@ -1,0 +1,372 @@
+// Context, options, scratch memory and per-call geometry of libgridhip (gfx950).
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace gridhip {
+
+int fail(gridhip_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int ws_reserve(gridhip_ctx *ctx, Workspace &ws, size_t bytes)
+{
+    if (bytes <= ws.bytes) return GRIDHIP_OK;
+    // growing scratch: the stream may still be reading the old block
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ws.ptr) GH_CHECK_HIP(ctx, hipFree(ws.ptr));
+    ws.ptr = nullptr;
+    ws.bytes = 0;
+    size_t want = bytes + bytes / 8 + 4096;  // head-room so nearby sizes do not reallocate
+    GH_CHECK_HIP(ctx, hipMalloc(&ws.ptr, want));
+    ws.bytes = want;
+    return GRIDHIP_OK;
+}
+
+static int next_pow2(int x)
+{
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+static int ilog2(int x)
+{
+    int l = 0;
+    while ((1 << l) < x) ++l;
+    return l;
+}
+
+// LDS row pitch (in cells) that keeps the two (or four) kernel rows a 32-lane group touches
+// on disjoint banks: 64-bit LDS accesses see 32 eight-byte bank pairs, so rows of rw lanes
+// must start rw bank pairs apart (MI355X_MICROARCH.md §LDS).
+static int lds_pitch(int lcols, int rw)
+{
+    if (rw >= 32) return (lcols + 1) & ~1;
+    int p = lcols;
+    while (p % 32 != rw) ++p;
+    return p;
+}
+
+size_t tables_bytes(const Geom &g)
+{
+    size_t ints = (size_t)g.nbins + ((size_t)g.nbins + 1) +
+                  (size_t)g.ngroups * ((size_t)g.ntiles + 1) + (size_t)g.nbins;
+    return ints * sizeof(int32_t);
+}
+
+Tables tables_of(gridhip_ctx *ctx, const Geom &g)
+{
+    Tables t;
+    int32_t *p = (int32_t *)ctx->tables.ptr;
+    t.bin_count = p;
+    p += g.nbins;
+    t.bin_start = p;
+    p += g.nbins + 1;
+    t.work_start = p;
+    p += (size_t)g.ngroups * (g.ntiles + 1);
+    t.cursor = p;
+    t.scalars = ctx->d_scalars;
+    return t;
+}
+
+int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh,
+              int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes)
+{
+    if (H <= 0 || Wd <= 0 || W <= 0 || Q <= 0 || gh <= 0 || gw <= 0)
+        return fail(ctx, GRIDHIP_EINVAL, "non-positive dimension");
+    if (H > (1 << 30) || Wd > (1 << 30) || W * Q * Q > (1LL << 30) || gh > 4096 || gw > 64)
+        return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside tile-kernel limits (gw<=64)");
+    memset(g, 0, sizeof *g);
+    g->H = H;
+    g->Wd = Wd;
+    g->W = (int32_t)W;
+    g->Q = (int32_t)Q;
+    g->gh = (int32_t)gh;
+    g->gw = (int32_t)gw;
+    g->rw = next_pow2((int)gw);
+    if (g->rw < 2) g->rw = 2;
+
+    const size_t lds_cap = (size_t)ctx->max_lds - 1024;
+    int T = (int)ctx->opt.tile;
+    auto lds_for = [&](int t) {
+        int lcols = t + (int)gw - 1, lrows = t + (int)gh - 1;
+        return (size_t)lds_pitch(lcols, g->rw) * lrows * 16;
+    };
+    if (T == 0) {
+        T = 64;
+        while (T > 8 && lds_for(T) > lds_cap) T >>= 1;
+        // small grids: keep enough tiles to occupy the chip
+        while (T > 16 && ((H + T - 1) / T) * ((Wd + T - 1) / T) < 1024) T >>= 1;
+    }
+    if (T < 8 || T > 128 || (T & (T - 1))) return fail(ctx, GRIDHIP_EINVAL, "tile must be a power of two in 8..128");
+    if (lds_for(T) > lds_cap)
+        return fail(ctx, GRIDHIP_EUNSUPPORTED, "tile %d with %lldx%lld kernel needs %zu B of LDS", T,
+                    (long long)gh, (long long)gw, lds_for(T));
+    g->T = T;
+    g->tshift = ilog2(T);
+    g->lcols = T + (int)gw - 1;
+    g->lrows = T + (int)gh - 1;
+    g->ldw = lds_pitch(g->lcols, g->rw);
+    g->offx = (((int)gw - 1 + T - 1) / T) * T;
+    g->offy = (((int)gh - 1 + T - 1) / T) * T;
+    g->ntx = (int)((Wd - 1 + g->offx) / T) + 1;
+    g->nty = (int)((H - 1 + g->offy) / T) + 1;
+    if ((int64_t)g->ntx * g->nty > (1 << 24)) return fail(ctx, GRIDHIP_EUNSUPPORTED, "too many tiles");
+    g->ntiles = g->ntx * g->nty;
+
+    int ng = (int)ctx->opt.wgroups;
+    if (ng == 0) ng = 1;
+    if (ng > W) ng = (int)W;
+    if (ng < 1 || ng > 8) return fail(ctx, GRIDHIP_EINVAL, "wgroups must be in 1..8");
+    g->ngroups = ng;
+    g->nbins = ng * g->ntiles;
+
+    int chunk = (int)ctx->opt.chunk;
+    if (chunk == 0) chunk = 2048;
+    if (chunk < 64) chunk = 64;
+    g->chunk = chunk;
+
+    *lds_bytes = lds_for(T);
+    int b = (int)ctx->opt.block;
+    if (b == 0) {
+        // one work-group per CU at T=64 (LDS-limited): use all 16 waves; smaller tiles
+        // co-reside, so give each fewer waves.
+        size_t per_cu = (size_t)ctx->max_lds / *lds_bytes;
+        b = per_cu >= 4 ? 256 : per_cu >= 2 ? 512 : 1024;
+    }
+    if (b < 64 || b > 1024 || (b & 63)) return fail(ctx, GRIDHIP_EINVAL, "block must be a multiple of 64 in 64..1024");
+    *block = b;
+    (void)n;
+    return GRIDHIP_OK;
+}
+
+}  // namespace gridhip
+
+using namespace gridhip;
+
+extern "C" {
+
+int gridhip_version(void) { return GRIDHIP_VERSION; }
+
+const char *gridhip_strerror(int code)
+{
+    switch (code) {
+        case GRIDHIP_OK: return "ok";
+        case GRIDHIP_EINVAL: return "invalid argument";
+        case GRIDHIP_ENOMEM: return "out of memory";
+        case GRIDHIP_EHIP: return "HIP runtime error";
+        case GRIDHIP_ENODEV: return "no usable device";
+        case GRIDHIP_EUNSUPPORTED: return "unsupported shape";
+        default: return "unknown error";
+    }
+}
+
+int gridhip_device_count(int *count)
+{
+    if (!count) return GRIDHIP_EINVAL;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return GRIDHIP_ENODEV;
+    }
+    *count = c;
+    return GRIDHIP_OK;
+}
+
+int gridhip_create(int device, gridhip_ctx **out)
+{
+    if (!out) return GRIDHIP_EINVAL;
+    *out = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return GRIDHIP_ENODEV;
+    if (device < 0 || device >= cnt) return GRIDHIP_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return GRIDHIP_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GRIDHIP_ENODEV;
+    gridhip_ctx *ctx = new (std::nothrow) gridhip_ctx();
+    if (!ctx) return GRIDHIP_ENOMEM;
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int maxlds = 0;
+    if (hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess &&
+        maxlds > 0)
+        ctx->max_lds = maxlds;
+    else
+        ctx->max_lds = 64 * 1024;
+    // CDNA4: 160 KiB of LDS per CU, all of it available to one work-group
+    if (strstr(prop.gcnArchName, "gfx950") && ctx->max_lds < 160 * 1024) ctx->max_lds = 160 * 1024;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return GRIDHIP_EHIP;
+    }
+    ctx->stream = ctx->own_stream;
+    if (hipMalloc((void **)&ctx->d_scalars, 16 * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(ctx->d_scalars, 0, 16 * sizeof(int32_t)) != hipSuccess) {
+        gridhip_destroy(ctx);
+        return GRIDHIP_ENOMEM;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
+            gridhip_destroy(ctx);
+            return GRIDHIP_EHIP;
+        }
+    *out = ctx;
+    return GRIDHIP_OK;
+}
+
+int gridhip_destroy(gridhip_ctx *ctx)
+{
+    if (!ctx) return GRIDHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    Workspace *all[] = {&ctx->recs, &ctx->keys, &ctx->tables, &ctx->stage};
+    for (Workspace *w : all)
+        if (w->ptr) (void)hipFree(w->ptr);
+    if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return GRIDHIP_OK;
+}
+
+const char *gridhip_last_error(const gridhip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int gridhip_set_stream(gridhip_ctx *ctx, void *s)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return GRIDHIP_OK;
+}
+
+void *gridhip_get_stream(gridhip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int gridhip_synchronize(gridhip_ctx *ctx)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GRIDHIP_OK;
+}
+
+static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
+{
+    if (!strcmp(key, "tile")) return &ctx->opt.tile;
+    if (!strcmp(key, "block")) return &ctx->opt.block;
+    if (!strcmp(key, "chunk")) return &ctx->opt.chunk;
+    if (!strcmp(key, "wgroups")) return &ctx->opt.wgroups;
+    if (!strcmp(key, "variant")) return &ctx->opt.variant;
+    if (!strcmp(key, "sort")) return &ctx->opt.sort;
+    return nullptr;
+}
+
+int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key) return GRIDHIP_EINVAL;
+    int64_t *s = opt_slot(ctx, key);
+    if (!s) return fail(ctx, GRIDHIP_EINVAL, "unknown option '%s'", key);
+    if (value < 0) return fail(ctx, GRIDHIP_EINVAL, "option '%s' must be >= 0", key);
+    *s = value;
+    return GRIDHIP_OK;
+}
+
+int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value)
+{
+    if (!ctx || !key || !value) return GRIDHIP_EINVAL;
+    int64_t *s = opt_slot(ctx, key);
+    if (!s) return fail(ctx, GRIDHIP_EINVAL, "unknown option '%s'", key);
+    *value = *s;
+    return GRIDHIP_OK;
+}
+
+int gridhip_malloc(gridhip_ctx *ctx, void **dptr, int64_t bytes)
+{
+    if (!ctx || !dptr || bytes < 0) return GRIDHIP_EINVAL;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    *dptr = nullptr;
+    if (bytes == 0) return GRIDHIP_OK;
+    GH_CHECK_HIP(ctx, hipMalloc(dptr, (size_t)bytes));
+    return GRIDHIP_OK;
+}
+
+int gridhip_free(gridhip_ctx *ctx, void *dptr)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    if (!dptr) return GRIDHIP_OK;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GH_CHECK_HIP(ctx, hipFree(dptr));
+    return GRIDHIP_OK;
+}
+
+int gridhip_memcpy_h2d(gridhip_ctx *ctx, void *dst, const void *src, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && (!dst || !src))) return GRIDHIP_EINVAL;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GRIDHIP_OK;
+}
+
+int gridhip_memcpy_d2h(gridhip_ctx *ctx, void *dst, const void *src, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && (!dst || !src))) return GRIDHIP_EINVAL;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GRIDHIP_OK;
+}
+
+int gridhip_memset(gridhip_ctx *ctx, void *dptr, int value, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && !dptr)) return GRIDHIP_EINVAL;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(dptr, value, (size_t)bytes, ctx->stream));
+    return GRIDHIP_OK;
+}
+
+int gridhip_enable_timing(gridhip_ctx *ctx, int enable)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    ctx->timing = enable != 0;
+    ctx->ev_valid = false;
+    return GRIDHIP_OK;
+}
+
+int gridhip_last_timing(gridhip_ctx *ctx, double *ms_total, double *ms_prepass, double *ms_kernel)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    if (!ctx->ev_valid) return fail(ctx, GRIDHIP_EINVAL, "no timed call recorded (gridhip_enable_timing)");
+    GH_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[2]));
+    float pre = 0.f, ker = 0.f;
+    GH_CHECK_HIP(ctx, hipEventElapsedTime(&pre, ctx->ev[0], ctx->ev[1]));
+    GH_CHECK_HIP(ctx, hipEventElapsedTime(&ker, ctx->ev[1], ctx->ev[2]));
+    if (ms_prepass) *ms_prepass = pre;
+    if (ms_kernel) *ms_kernel = ker;
+    if (ms_total) *ms_total = (double)pre + (double)ker;
+    return GRIDHIP_OK;
+}
+
+int gridhip_last_dropped(gridhip_ctx *ctx, int64_t *dropped)
+{
+    if (!ctx || !dropped) return GRIDHIP_EINVAL;
+    *dropped = 0;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t h = 0;
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_scalars, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *dropped = h;
+    return GRIDHIP_OK;
+}
+
+}  // extern "C"

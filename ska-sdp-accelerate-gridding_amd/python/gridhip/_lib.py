@@ -1,0 +1,79 @@
+"""ctypes loader for libgridhip.so (the C ABI declared in include/gridhip.h).
+
+There is no CPU fallback: if the HIP library has not been built this module raises, and every
+compute entry point needs a gfx950 device.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(_PKG, "..", ".."))          # ska-sdp-accelerate-gridding_amd/
+LIB_PATH = os.path.join(ROOT, "lib", "libgridhip.so")
+
+i64 = C.c_int64
+vp = C.c_void_p
+ci = C.c_int
+
+OK = 0
+EINVAL, ENOMEM, EHIP, ENODEV, EUNSUPPORTED = -1, -2, -3, -4, -5
+
+# name -> (restype, argtypes); mirrors include/gridhip.h one to one
+_GRID_DEV = [vp, i64, i64, vp, i64, vp, vp, i64, vp]
+_CONV_DEV = [vp, i64, i64, vp, i64, i64, i64, i64, vp, vp, vp, i64, vp]
+_CONV2_DEV = [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp, vp]
+SIGNATURES = {
+    "gridhip_version": (ci, []),
+    "gridhip_strerror": (C.c_char_p, [ci]),
+    "gridhip_device_count": (ci, [C.POINTER(ci)]),
+    "gridhip_create": (ci, [ci, C.POINTER(vp)]),
+    "gridhip_destroy": (ci, [vp]),
+    "gridhip_last_error": (C.c_char_p, [vp]),
+    "gridhip_set_stream": (ci, [vp, vp]),
+    "gridhip_get_stream": (vp, [vp]),
+    "gridhip_synchronize": (ci, [vp]),
+    "gridhip_set_option": (ci, [vp, C.c_char_p, i64]),
+    "gridhip_get_option": (ci, [vp, C.c_char_p, C.POINTER(i64)]),
+    "gridhip_last_dropped": (ci, [vp, C.POINTER(i64)]),
+    "gridhip_grid": (ci, _GRID_DEV),
+    "gridhip_convgrid": (ci, _CONV_DEV),
+    "gridhip_convgrid2": (ci, _CONV2_DEV),
+    "gridhip_degrid2": (ci, _CONV2_DEV),
+    "gridhip_grid_dev": (ci, _GRID_DEV),
+    "gridhip_convgrid_dev": (ci, _CONV_DEV),
+    "gridhip_convgrid2_dev": (ci, _CONV2_DEV),
+    "gridhip_degrid2_dev": (ci, _CONV2_DEV),
+    "gridhip_malloc": (ci, [vp, C.POINTER(vp), i64]),
+    "gridhip_free": (ci, [vp, vp]),
+    "gridhip_memcpy_h2d": (ci, [vp, vp, vp, i64]),
+    "gridhip_memcpy_d2h": (ci, [vp, vp, vp, i64]),
+    "gridhip_memset": (ci, [vp, vp, ci, i64]),
+    "gridhip_last_timing": (ci, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gridhip_enable_timing": (ci, [vp, ci]),
+}
+
+_lib = None
+
+
+class GridHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gridhip error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load libgridhip.so and attach prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ska-sdp-accelerate-gridding_amd/csrc`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

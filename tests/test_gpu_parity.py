@@ -1,0 +1,279 @@
+"""GPU parity: libgridhip (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): grids within 1e-10 relative of the CPU reference,
+measured as max|G_gpu - G_ref| / max|G_ref|.  fp64 atomics make the summation order differ
+from the oracle's, so results are a tolerance, never bit-exact; observed error is ~1e-15.
+Integer work (cell / sub-cell indices) must match exactly — it shows up as O(1) grid errors
+when it does not.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def case(seed, N, M, W, Q, gh, gw, n, spread=0.56, dist="uniform"):
+    rng = np.random.default_rng(seed)
+    gcf = rng.normal(size=(W, Q, Q, gh, gw)) + 1j * rng.normal(size=(W, Q, Q, gh, gw))
+    if dist == "uniform":
+        u = rng.uniform(-spread, spread, n)
+        v = rng.uniform(-spread, spread, n)
+    else:  # centrally concentrated: heavy same-tile contention
+        u = np.clip(rng.normal(0, 0.03, n), -0.6, 0.6)
+        v = np.clip(rng.normal(0, 0.03, n), -0.6, 0.6)
+    wb = rng.integers(0, W, n)
+    vis = rng.normal(size=n) + 1j * rng.normal(size=n)
+    return gcf, u, v, wb, vis
+
+
+SHAPES = [
+    # N(rows) M(cols) W  Q  gh  gw   n
+    (64, 64, 3, 4, 7, 7, 3000),
+    (256, 256, 8, 8, 15, 15, 20000),
+    (128, 96, 2, 2, 5, 9, 5000),        # non-square grid, non-square kernel
+    (96, 160, 4, 3, 9, 5, 5000),
+    (200, 200, 2, 2, 31, 31, 2000),     # the support the reference's test scripts use (S=31)
+    (64, 64, 1, 1, 1, 1, 1000),
+    (50, 50, 5, 2, 3, 3, 4000),
+    (33, 47, 2, 4, 2, 4, 2000),         # even supports, odd grid sizes
+    (300, 300, 16, 8, 15, 15, 50000),
+]
+
+
+@pytest.mark.parametrize("N,M,W,Q,gh,gw,n", SHAPES)
+def test_convgrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
+    gcf, u, v, wb, vis = case(N * 7 + gw, N, M, W, Q, gh, gw, n)
+    ref = oracle.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), u, v, wb, vis)
+    got = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
+    assert rel(got, ref) < TOL
+    assert ctx.last_dropped() == 0
+
+
+@pytest.mark.parametrize("tile,block,wgroups,chunk", [(8, 64, 1, 64), (16, 256, 2, 100), (32, 512, 4, 512),
+                                                      (64, 1024, 8, 4096), (64, 256, 1, 0), (32, 1024, 8, 64)])
+def test_tuning_knobs_do_not_change_results(ctx, oracle, tile, block, wgroups, chunk):
+    N, W, Q, S, n = 200, 8, 4, 15, 30000
+    gcf, u, v, wb, vis = case(99, N, N, W, Q, S, S, n)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis)
+    try:
+        for k, val in (("tile", tile), ("block", block), ("wgroups", wgroups), ("chunk", chunk)):
+            ctx.set_option(k, val)
+        got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+    finally:
+        for k in ("tile", "block", "wgroups", "chunk"):
+            ctx.set_option(k, 0)
+    assert rel(got, ref) < TOL
+
+
+def test_direct_variant_matches_oracle(ctx, oracle):
+    N, W, Q, S, n = 128, 4, 4, 7, 20000
+    gcf, u, v, wb, vis = case(5, N, N, W, Q, S, S, n)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis)
+    ctx.set_option("variant", 1)
+    try:
+        got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+    finally:
+        ctx.set_option("variant", 0)
+    assert rel(got, ref) < TOL
+
+
+def test_concentrated_distribution(ctx, oracle):
+    """Distribution B of SURVEY.md §8d: everything lands in a handful of tiles."""
+    N, W, Q, S, n = 512, 8, 8, 15, 60000
+    gcf, u, v, wb, vis = case(21, N, N, W, Q, S, S, n, dist="core")
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis)
+    got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+    assert rel(got, ref) < TOL
+
+
+def test_accumulates_into_existing_grid(ctx, oracle):
+    """permute (+) a: the destination is added to, not overwritten (src/Gridding.hs:244)."""
+    N, W, Q, S, n = 96, 2, 2, 7, 4000
+    gcf, u, v, wb, vis = case(3, N, N, W, Q, S, S, n)
+    rng = np.random.default_rng(4)
+    G0 = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    ref = oracle.convgrid2(gcf, G0.copy(), u, v, wb, vis)
+    got = ctx.convgrid2(gcf, G0.copy(), (u, v, None), wb, vis)
+    assert rel(got, ref) < TOL
+    # twice more onto the same grid
+    ref = oracle.convgrid2(gcf, ref, u, v, wb, vis)
+    got = ctx.convgrid2(gcf, got, (u, v, None), wb, vis)
+    assert rel(got, ref) < TOL
+
+
+def test_uvw_matrix_layout(ctx, oracle):
+    """(n,3) row-major /vis/uvw matrix sliced by column (src/ImageDataset.hs:51-53, 94-97)."""
+    N, W, Q, S, n = 96, 2, 2, 7, 4000
+    gcf, u, v, wb, vis = case(8, N, N, W, Q, S, S, n)
+    uvw = np.stack([u, v, np.zeros(n)], axis=1)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis)
+    got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), uvw, wb, vis)
+    assert rel(got, ref) < TOL
+
+
+def test_edges_empty_and_out_of_range(ctx, oracle):
+    N, W, Q, S = 64, 2, 2, 7
+    gcf, u, v, wb, vis = case(12, N, N, W, Q, S, S, 16)
+    z = lambda: np.zeros((N, N), dtype=np.complex128)
+    # n = 0
+    assert not ctx.convgrid2(gcf, z(), (u[:0], v[:0], None), wb[:0], vis[:0]).any()
+    # everything far outside: dropped, never wrapped (fixoutofbounds, src/Gridding.hs:883-891)
+    far = np.array([0.9, -0.9, 3.0, -1e6, 1e300, -1e300])
+    assert not ctx.convgrid2(gcf, z(), (far, far[::-1].copy(), None), np.zeros(6, np.int64), np.ones(6, complex)).any()
+    # NaN coordinates are skipped
+    nanu = np.array([np.nan, 0.1, np.inf])
+    nanv = np.array([0.1, np.nan, 0.0])
+    assert not ctx.convgrid2(gcf, z(), (nanu, nanv, None), np.zeros(3, np.int64), np.ones(3, complex)).any()
+    # footprints straddling each edge and corner: only the in-range part is filled
+    eu = np.array([-0.5, 0.4999, 0.0, 0.0, -0.5, 0.4999, -0.53, 0.54])
+    ev = np.array([0.0, 0.0, -0.5, 0.4999, -0.5, 0.4999, 0.2, -0.3])
+    ewb = np.array([0, 1, 0, 1, 0, 1, 0, 1])
+    evis = np.arange(1, 9) * (1 + 0.5j)
+    ref = oracle.convgrid2(gcf, z(), eu, ev, ewb, evis)
+    got = ctx.convgrid2(gcf, z(), (eu, ev, None), ewb, evis)
+    assert ref.any() and rel(got, ref) < TOL
+    # wbin outside [0, W): skipped and counted (the reference would read out of range)
+    bad = np.array([0, W, -1, 1])
+    got = ctx.convgrid2(gcf, z(), (u[:4], v[:4], None), bad, vis[:4])
+    ref = oracle.convgrid2(gcf, z(), u[[0, 3]], v[[0, 3]], bad[[0, 3]], vis[[0, 3]])
+    assert rel(got, ref) < TOL and ctx.last_dropped() == 2
+
+
+def test_index_parity_near_boundaries(ctx, oracle):
+    """Coordinates a hair away from cell / sub-cell boundaries must pick the oracle's cell."""
+    N, Q, S = 64, 8, 3
+    rng = np.random.default_rng(33)
+    gcf = rng.normal(size=(1, Q, Q, S, S)) + 1j * rng.normal(size=(1, Q, Q, S, S))
+    k = rng.integers(-30 * Q, 30 * Q, 4000)
+    # sub-cell boundaries sit at (k + 0.5)/Q cells; nudge by +-1e-9 cells
+    base = (k + 0.5) / Q
+    pu = (base + rng.choice([-1e-9, 1e-9], 4000)) / N
+    pv = rng.uniform(-0.4, 0.4, 4000)
+    vis = rng.normal(size=4000) + 1j * rng.normal(size=4000)
+    wb = np.zeros(4000, np.int64)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), pu, pv, wb, vis)
+    got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (pu, pv, None), wb, vis)
+    assert rel(got, ref) < TOL
+
+
+def test_convgrid_and_grid(ctx, oracle):
+    N, Q, S, n = 128, 4, 7, 10000
+    gcf, u, v, wb, vis = case(17, N, N, 1, Q, S, S, n)
+    ref = oracle.convgrid(gcf[0], np.zeros((N, N), dtype=np.complex128), u, v, vis)
+    got = ctx.convgrid(gcf[0], np.zeros((N, N), dtype=np.complex128), (u, v, None), vis)
+    assert rel(got, ref) < TOL
+    ref = oracle.grid(np.zeros((N, N), dtype=np.complex128), u, v, vis)
+    got = ctx.grid(np.zeros((N, N), dtype=np.complex128), (u, v, None), vis)
+    assert rel(got, ref) < TOL
+
+
+def test_golden_fixtures(ctx, golden):
+    g = golden("brokennumbers")  # the reference's own recorded output
+    G = np.zeros((5, 5), dtype=np.complex128)
+    for _ in range(int(g["passes"])):
+        ctx.grid(G, ((g["x"] - 2) / 5.0, (g["y"] - 2) / 5.0, None), g["val"])
+    assert np.array_equal(G, g["expected"])
+    g = golden("fixbounds2")
+    G = ctx.convgrid(g["gcf"], np.zeros((5, 5), dtype=np.complex128), (g["pu"], g["pv"], None), g["vis"])
+    assert np.array_equal(G, g["expected"])
+    g = golden("convgrid2_small")
+    N = g["expected"].shape[0]
+    G = ctx.convgrid2(g["gcf"], np.zeros((N, N), dtype=np.complex128), (g["u"], g["v"], None), g["wbin"], g["vis"])
+    assert rel(G, g["expected"]) < TOL
+    d = ctx.degrid2(g["gcf"], g["expected"].copy(), (g["u"], g["v"], None), g["wbin"])
+    assert rel(d, g["degrid"]) < TOL
+
+
+@pytest.mark.parametrize("N,M,W,Q,gh,gw,n", SHAPES[:5])
+def test_degrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
+    gcf, u, v, wb, vis = case(N + gw, N, M, W, Q, gh, gw, n)
+    rng = np.random.default_rng(1)
+    G = rng.normal(size=(N, M)) + 1j * rng.normal(size=(N, M))
+    ref = oracle.degrid2(gcf, G, u, v, wb)
+    got = ctx.degrid2(gcf, G, (u, v, None), wb)
+    assert rel(got, ref) < TOL
+
+
+def test_adjointness_on_device(ctx):
+    """<g, grid(vis)> == <degrid_{conj K}(g), vis> — ties the two kernels together."""
+    N, W, Q, S, n = 160, 4, 4, 9, 20000
+    gcf, u, v, wb, vis = case(77, N, N, W, Q, S, S, n)
+    rng = np.random.default_rng(2)
+    g = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    G = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+    d = ctx.degrid2(np.conj(gcf), g, (u, v, None), wb)
+    lhs, rhs = np.vdot(g, G), np.vdot(d, vis)
+    assert abs(lhs - rhs) / abs(lhs) < 1e-11
+
+
+def test_device_path_with_torch_tensors(ctx, oracle):
+    import torch
+    N, W, Q, S, n = 256, 8, 8, 15, 40000
+    gcf, u, v, wb, vis = case(55, N, N, W, Q, S, S, n)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    ctx.enable_timing(True)
+    ctx.convgrid2(t(gcf), G, (t(u), t(v), None), t(wb), t(vis))
+    total, pre, ker = ctx.last_timing()
+    ctx.enable_timing(False)
+    torch.cuda.synchronize()
+    assert rel(G.cpu().numpy(), ref) < TOL
+    assert total > 0 and ker > 0
+    d = ctx.degrid2(t(gcf), G, (t(u), t(v), None), t(wb))
+    torch.cuda.synchronize()
+    assert rel(d.cpu().numpy(), oracle.degrid2(gcf, ref, u, v, wb)) < 1e-9
+
+
+def test_baseline_config2_full_size(ctx, oracle):
+    """BASELINE.json configs[1]: 10^6 vis, 2048^2 grid, 7x7 support — small enough to compare outright."""
+    N, W, Q, S, n = 2048, 16, 8, 7, 1_000_000
+    gcf, u, v, wb, vis = case(2026, N, N, W, Q, S, S, n, spread=0.49)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+    got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+    assert rel(got, ref) < TOL
+
+
+def test_checksum_property_large(ctx):
+    """Size-independent check at a large n (15x15, 128 planes): with every tap in range,
+    sum(G) == sum_k vis_k * sum_ij K[slice_k]; linearity in vis holds between two runs."""
+    import torch
+    dev = torch.device("cuda:0")
+    N, W, Q, S, n = 2048, 128, 8, 15, 4_000_000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    m = (S / 2 + 1) / N
+    u = (torch.rand(n, generator=gen, device=dev, dtype=torch.float64) - 0.5) * (1 - 2 * m)
+    v = (torch.rand(n, generator=gen, device=dev, dtype=torch.float64) - 0.5) * (1 - 2 * m)
+    wb = torch.randint(0, W, (n,), generator=gen, device=dev, dtype=torch.int64)
+    vis = torch.complex(torch.randn(n, generator=gen, device=dev, dtype=torch.float64),
+                        torch.randn(n, generator=gen, device=dev, dtype=torch.float64))
+    gcf = torch.complex(torch.randn((W, Q, Q, S, S), generator=gen, device=dev, dtype=torch.float64),
+                        torch.randn((W, Q, Q, S, S), generator=gen, device=dev, dtype=torch.float64))
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+    torch.cuda.synchronize()
+    # slice index per visibility, recomputed with torch in fp64 (same formula as frac_coord)
+    def fc(p):
+        x = N // 2 + p * N
+        fl = torch.floor(x + 0.5 / Q)
+        fr = torch.round((x - fl) * Q).clamp(0, Q - 1)
+        return fl.long(), fr.long()
+    _, xf = fc(u)
+    _, yf = fc(v)
+    ksum = gcf.sum(dim=(3, 4))[wb, yf, xf]
+    expect = (vis * ksum).sum()
+    got = G.sum()
+    scale = (vis.abs() * gcf.abs().sum(dim=(3, 4))[wb, yf, xf]).sum()
+    assert abs((got - expect).item()) / scale.item() < 1e-12
+    G2 = torch.zeros_like(G)
+    ctx.convgrid2(gcf, G2, (u, v, None), wb, -2.0 * vis)
+    torch.cuda.synchronize()
+    assert ((G2 + 2.0 * G).abs().max() / G.abs().max()).item() < 1e-12
