@@ -70,6 +70,14 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C ska-sdp-accelerate-gridding_amd/csrc`). There is no CPU fallback."
         )
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7 and loads
+    # it by path, so a system copy loaded first would leave torch a second runtime that finds
+    # no GPUs.  Importing torch first makes libgridhip's NEEDED libamdhip64.so.7 resolve (by
+    # SONAME) to the copy torch uses.  Callers without torch (C, Haskell) get the system one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
