@@ -66,7 +66,7 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
     if (!gcf || (n > 0 && !vis)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
     if (W <= 0 || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel shape");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->opt.variant == 1 || gw > 64) {
+    if (ctx->opt.variant == 1) {
         mark(ctx, 0);
         mark(ctx, 1);
         GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
@@ -77,14 +77,24 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
     Geom g;
     int block;
     size_t lds;
-    GH_CHECK(make_geom(ctx, H, Wd, W, Q, gh, gw, n, &g, &block, &lds));
+    int rc = make_geom(ctx, H, Wd, W, Q, gh, gw, n, &g, &block, &lds);
+    if (rc == GRIDHIP_EUNSUPPORTED && ctx->opt.tile == 0) {
+        // support too large for an LDS tile: direct global-atomic scatter
+        mark(ctx, 0);
+        mark(ctx, 1);
+        GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
+        mark(ctx, 2);
+        ctx->ev_valid = ctx->timing;
+        return GRIDHIP_OK;
+    }
+    GH_CHECK(rc);
     // scratch is sized before the timed region begins
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
     mark(ctx, 0);
-    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin, vis));
+    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin));
     mark(ctx, 1);
-    if (n > 0) GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, grid));
+    if (n > 0) GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, vis, grid));
     mark(ctx, 2);
     ctx->ev_valid = ctx->timing;
     return GRIDHIP_OK;
@@ -115,7 +125,7 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     mark(ctx, 0);
     // visibilities with no tap inside the grid (or an out-of-range wbin) predict 0
     if (n > 0) GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)n * 16, ctx->stream));
-    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin, nullptr));
+    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin));
     mark(ctx, 1);
     if (n > 0) GH_CHECK(launch_tile_degrid(ctx, g, block, lds, n, gcf, grid, vis_out));
     mark(ctx, 2);

@@ -42,7 +42,7 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
     const int32_t X = (int32_t)x0 + g.offx, Y = (int32_t)y0 + g.offy;
     const int32_t tx = X >> g.tshift, ty = Y >> g.tshift;  // X, Y >= 0 by construction of offx/offy
     const int32_t lx = X & (g.T - 1), ly = Y & (g.T - 1);
-    const int32_t grp = (int32_t)((wb * g.ngroups) / g.W);
+    const int32_t grp = ((int32_t)wb * g.ngroups) / g.W;  // 32-bit: W * ngroups < 2^31
     o.bin = grp * g.ntiles + ty * g.ntx + tx;
     o.lxy = (ly << 16) | lx;
     o.kslice = ((int32_t)wb * g.Q + yf) * g.Q + xf;
@@ -166,7 +166,6 @@ template <bool LDS_HIST>
 __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
                                                            const double *__restrict__ v, int64_t stride,
                                                            const int64_t *__restrict__ wbin,
-                                                           const double *__restrict__ vis,
                                                            const int32_t *__restrict__ bin_start,
                                                            int32_t *__restrict__ cursor,
                                                            VisRec *__restrict__ recs)
@@ -202,20 +201,14 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
         VisRec r;
         r.lxy = b.lxy;
         r.kslice = b.kslice;
-        r.vr = vis ? vis[2 * k] : 0.0;
-        r.vi = vis ? vis[2 * k + 1] : 0.0;
         r.orig = (int32_t)k;
         r.pad = 0;
-        // 32-B record as two 16-B stores
-        int4 *dst = reinterpret_cast<int4 *>(recs + slot);
-        const int4 *src = reinterpret_cast<const int4 *>(&r);
-        dst[0] = src[0];
-        dst[1] = src[1];
+        *reinterpret_cast<int4 *>(recs + slot) = *reinterpret_cast<const int4 *>(&r);  // one 16-B store
     }
 }
 
 int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
-               int64_t uv_stride, const int64_t *wbin, const double *vis)
+               int64_t uv_stride, const int64_t *wbin)
 {
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
@@ -250,10 +243,10 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
                        t.work_start, t.cursor);
     if (lds_hist)
         hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n,
-                           u, v, uv_stride, wbin, vis, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
+                           u, v, uv_stride, wbin, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
     else
         hipLaunchKernelGGL(bin_scatter_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, vis, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
+                           uv_stride, wbin, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }

@@ -9,16 +9,18 @@
 
 namespace gridhip {
 
-// One visibility after the binning pre-pass: everything the tile kernels need, 32 B so a
-// wave fetches it with one scalar load (s_load_dwordx8).
-struct __attribute__((aligned(32))) VisRec {
+// One visibility after the binning pre-pass: where its footprint starts inside the tile, which
+// kernel slice it uses and where its value lives in the caller's array.  16 B, so a wave
+// fetches it with one scalar load (s_load_dwordx4) and the pre-pass writes it with one store.
+// Records do not depend on the visibility values: the image and PSF passes of do_imaging
+// (src/Gridding.hs:538,541) can share one binning.
+struct __attribute__((aligned(16))) VisRec {
     int32_t lxy;     // ly0 << 16 | lx0 : footprint origin relative to the tile's LDS region
     int32_t kslice;  // (wbin*Q + yf)*Q + xf : which [gh][gw] kernel slice
-    double vr, vi;   // visibility
-    int32_t orig;    // index in the caller's arrays (degrid writes there)
+    int32_t orig;    // index in the caller's arrays (vis is gathered from / degrid writes there)
     int32_t pad;
 };
-static_assert(sizeof(VisRec) == 32, "VisRec must be 32 bytes");
+static_assert(sizeof(VisRec) == 16, "VisRec must be 16 bytes");
 
 // Geometry of one gridding call, shared by host and device code.
 struct Geom {
@@ -33,12 +35,12 @@ struct Geom {
     int32_t nbins;
     int32_t ldw;          // LDS row pitch in cells
     int32_t lrows, lcols; // valid LDS region: T+gh-1 rows, T+gw-1 columns
-    int32_t rw;           // lanes per kernel row (power of two >= gw)
     int32_t chunk;        // max visibilities per work item
+    int32_t dbg;          // ablation switch for tuning runs (0 = off)
 };
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0;
 };
 
 struct Workspace {
@@ -122,9 +124,9 @@ __device__ __forceinline__ void frac_coord_dev(int64_t n, int32_t qpx, double p,
 
 // kernel launchers (each enqueues on ctx->stream)
 int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
-               int64_t uv_stride, const int64_t *wbin, const double *vis);
+               int64_t uv_stride, const int64_t *wbin);
 int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int64_t n,
-                     const double *gcf, double *grid);
+                     const double *gcf, const double *vis, double *grid);
 int launch_tile_degrid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int64_t n,
                        const double *gcf, const double *grid, double *vis_out);
 int launch_direct_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,

@@ -31,13 +31,6 @@ int ws_reserve(gridhip_ctx *ctx, Workspace &ws, size_t bytes)
     return GRIDHIP_OK;
 }
 
-static int next_pow2(int x)
-{
-    int p = 1;
-    while (p < x) p <<= 1;
-    return p;
-}
-
 static int ilog2(int x)
 {
     int l = 0;
@@ -45,14 +38,14 @@ static int ilog2(int x)
     return l;
 }
 
-// LDS row pitch (in cells) that keeps the two (or four) kernel rows a 32-lane group touches
-// on disjoint banks: 64-bit LDS accesses see 32 eight-byte bank pairs, so rows of rw lanes
-// must start rw bank pairs apart (MI355X_MICROARCH.md §LDS).
-static int lds_pitch(int lcols, int rw)
+// LDS row pitch (in cells).  Lanes take consecutive taps t -> (t / gw, t % gw); 64-bit LDS
+// accesses are serviced 32 lanes at a time over 32 eight-byte bank pairs, so with
+// pitch == gw (mod 32) tap t lands on bank pair (origin + t) mod 32 and any 32 consecutive taps
+// are conflict-free, row breaks included (MI355X_MICROARCH.md §LDS).
+static int lds_pitch(int lcols, int gw)
 {
-    if (rw >= 32) return (lcols + 1) & ~1;
     int p = lcols;
-    while (p % 32 != rw) ++p;
+    while (p % 32 != gw % 32) ++p;
     return p;
 }
 
@@ -83,8 +76,8 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
 {
     if (H <= 0 || Wd <= 0 || W <= 0 || Q <= 0 || gh <= 0 || gw <= 0)
         return fail(ctx, GRIDHIP_EINVAL, "non-positive dimension");
-    if (H > (1 << 30) || Wd > (1 << 30) || W * Q * Q > (1LL << 30) || gh > 4096 || gw > 64)
-        return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside tile-kernel limits (gw<=64)");
+    if (H > (1 << 30) || Wd > (1 << 30) || W * Q * Q > (1LL << 30) || gh > 1024 || gw > 1024)
+        return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside tile-kernel limits");
     memset(g, 0, sizeof *g);
     g->H = H;
     g->Wd = Wd;
@@ -92,14 +85,12 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->Q = (int32_t)Q;
     g->gh = (int32_t)gh;
     g->gw = (int32_t)gw;
-    g->rw = next_pow2((int)gw);
-    if (g->rw < 2) g->rw = 2;
 
     const size_t lds_cap = (size_t)ctx->max_lds - 1024;
     int T = (int)ctx->opt.tile;
     auto lds_for = [&](int t) {
         int lcols = t + (int)gw - 1, lrows = t + (int)gh - 1;
-        return (size_t)lds_pitch(lcols, g->rw) * lrows * 16;
+        return (size_t)lds_pitch(lcols, (int)gw) * lrows * 16;
     };
     if (T == 0) {
         T = 64;
@@ -115,7 +106,7 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->tshift = ilog2(T);
     g->lcols = T + (int)gw - 1;
     g->lrows = T + (int)gh - 1;
-    g->ldw = lds_pitch(g->lcols, g->rw);
+    g->ldw = lds_pitch(g->lcols, (int)gw);
     g->offx = (((int)gw - 1 + T - 1) / T) * T;
     g->offy = (((int)gh - 1 + T - 1) / T) * T;
     g->ntx = (int)((Wd - 1 + g->offx) / T) + 1;
@@ -123,17 +114,22 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     if ((int64_t)g->ntx * g->nty > (1 << 24)) return fail(ctx, GRIDHIP_EUNSUPPORTED, "too many tiles");
     g->ntiles = g->ntx * g->nty;
 
+    // w-plane groups: work items of group g run on XCD g (blockIdx round-robin), so that XCD's
+    // 4 MiB L2 only has to hold W/8 planes of the kernel table instead of all of them (measured:
+    // 1.7x on the 128-plane 15x15 case).  Every (group, tile) pair flushes its tile once, so it
+    // only pays when there are enough visibilities per pair to amortise that.
     int ng = (int)ctx->opt.wgroups;
-    if (ng == 0) ng = 1;
+    if (ng == 0) ng = (W >= 8 && n / ((int64_t)g->ntiles * 8) >= 256) ? 8 : 1;
     if (ng > W) ng = (int)W;
     if (ng < 1 || ng > 8) return fail(ctx, GRIDHIP_EINVAL, "wgroups must be in 1..8");
     g->ngroups = ng;
     g->nbins = ng * g->ntiles;
 
     int chunk = (int)ctx->opt.chunk;
-    if (chunk == 0) chunk = 2048;
+    if (chunk == 0) chunk = 8192;
     if (chunk < 64) chunk = 64;
     g->chunk = chunk;
+    g->dbg = (int32_t)ctx->opt.dbg;
 
     *lds_bytes = lds_for(T);
     int b = (int)ctx->opt.block;
@@ -267,6 +263,7 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "wgroups")) return &ctx->opt.wgroups;
     if (!strcmp(key, "variant")) return &ctx->opt.variant;
     if (!strcmp(key, "sort")) return &ctx->opt.sort;
+    if (!strcmp(key, "dbg")) return &ctx->opt.dbg;
     return nullptr;
 }
 

@@ -3,13 +3,14 @@
 //
 // One work item = (w-group, grid tile, chunk of <=chunk binned visibilities).  A work-group
 // keeps the tile plus its kernel-support halo — (T+gh-1) x (T+gw-1) complex cells, planar
-// re/im, 100 KB at T=64, 15x15 — in LDS (160 KB per CU).  Each wave takes one visibility at a
-// time: its 32-byte record arrives by scalar load, lanes map to kernel taps (rw lanes per
-// kernel row, 64/rw rows per step) so the tap read from the [gh][gw] slice is one coalesced
-// run and the accumulate is a conflict-free ds_add_f64 (row pitch chosen in ctx.hip).  The
-// grid read-modify-write of the reference's `permute (+)` therefore never leaves the CU; HBM
-// sees the tile once, when the work-group flushes it with global_atomic_add_f64 (neighbouring
-// tiles overlap in their halos, and several chunks/groups may share a tile).
+// re/im, 35 KB at T=32 / 100 KB at T=64 for 15x15 — in LDS (160 KB per CU).  Each wave takes
+// one visibility at a time: its 16-byte record and its value arrive by broadcast loads, lanes map
+// to kernel taps (64 consecutive taps per step) so the tap read from the [gh][gw] slice is one
+// coalesced run and the accumulate is a conflict-free ds_add_f64 (row pitch chosen in ctx.hip).  The grid read-modify-write of the reference's `permute (+)`
+// therefore never leaves the CU; HBM sees the tile once, when the work-group flushes it with
+// global_atomic_add_f64 (neighbouring tiles overlap in their halos, and several chunks/groups
+// may share a tile).  The next visibility's taps are fetched while the current one is being
+// accumulated.
 //
 // fixoutofbounds (:883-891): the LDS region may hang over the grid edge; cells outside the
 // grid are simply not flushed, i.e. out-of-range taps are dropped, never wrapped.
@@ -48,26 +49,35 @@ __device__ __forceinline__ bool find_work(const Geom &g, const int32_t *__restri
     return true;
 }
 
+// All lanes of the wave read the same 16 bytes (one broadcast transaction).  Vector loads on
+// purpose: scalar loads share the lgkmcnt counter with the LDS atomics and would make every
+// record fetch wait for the wave's outstanding ds_add_f64s.
 __device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int idx)
 {
-    // idx is wave-uniform: let the compiler use scalar loads
-    const int4 *p = reinterpret_cast<const int4 *>(recs + idx);
-    int4 a = p[0], b = p[1];
+    const int4 a = *reinterpret_cast<const int4 *>(recs + idx);
     VisRec r;
     r.lxy = a.x;
     r.kslice = a.y;
-    r.vr = __hiloint2double(a.w, a.z);
-    r.vi = __hiloint2double(b.y, b.x);
-    r.orig = b.z;
+    r.orig = a.z;
     r.pad = 0;
     return r;
 }
 
-template <int RW>
+// Lane -> tap mapping: tap t = step*64 + lane, (i, j) = (t / gw, t % gw).  Taps of one slice
+// are contiguous in memory, so a step reads one coalesced 1 KiB run; with the LDS row pitch
+// congruent to gw modulo 32 (ctx.hip) tap t falls on 8-byte bank pair t mod 32, so the 32
+// lanes an LDS instruction services together never conflict, whatever the footprint origin.
+//
+// S > 0: square S x S support known at compile time — fully unrolled, software-pipelined per
+// wave (record two visibilities ahead, taps + value one ahead, accumulate the current one).
+// S == 0: any gh x gw.
+// DBG (tuning builds only): 1 = skip the LDS atomics, 2 = every visibility reads slice 0, 3 = both.
+template <int S, int DBG>
 __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *__restrict__ recs,
                                                          const int32_t *__restrict__ bin_start,
                                                          const int32_t *__restrict__ work_start,
                                                          const double2 *__restrict__ gcf,
+                                                         const double2 *__restrict__ vis,
                                                          double *__restrict__ grid)
 {
     extern __shared__ double lds[];
@@ -82,27 +92,108 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
     }
     __syncthreads();
 
-    constexpr int RPI = 64 / RW;  // kernel rows per wave step
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = tid >> 6;
     const int nw = blockDim.x >> 6;
-    const int j = lane % RW, ri = lane / RW;
-    const bool jok = j < g.gw;
-    const int S2 = g.gh * g.gw;
+    const int gh = S ? S : g.gh, gw = S ? S : g.gw;
+    const int S2 = gh * gw;
     double *lre = lds, *lim = lds + plane;
 
-    for (int vi = w.v_lo + wave; vi < w.v_hi; vi += nw) {
-        const VisRec r = load_rec(recs, __builtin_amdgcn_readfirstlane(vi));
-        const double2 *kp = gcf + (size_t)r.kslice * S2 + j;
-        const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff) + j;
-        for (int i = ri; i < g.gh; i += RPI) {
-            if (jok) {
-                const double2 kv = kp[i * g.gw];
-                const double re = r.vr * kv.x - r.vi * kv.y;
-                const double im = r.vr * kv.y + r.vi * kv.x;
-                const int a = lbase + i * g.ldw;
+    if (S > 0) {
+        constexpr int NSTEP = S ? (S * S + 63) / 64 : 1;
+        constexpr int TAIL = S * S - (NSTEP - 1) * 64;  // lanes with a tap in the last step
+        // Per-lane LDS offsets of this lane's taps.  The loop below is branch-free: a lane
+        // without a tap in the last step (lane >= TAIL) reads tap 0 (valid memory) and adds 0.0
+        // to the cell of tap lane-32, which sits on a bank pair none of the step's real taps
+        // use.  (A divergent tail block would hide its s_waitcnt from the other path and make
+        // the compiler drain every outstanding load at the loop head.)
+        int loff[NSTEP];
+        const bool tail_ok = lane < TAIL || TAIL == 64;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            int t = s * 64 + lane;
+            if (s == NSTEP - 1 && !tail_ok) t = lane - 32;
+            loff[s] = (t / S) * g.ldw + (t % S);
+        }
+        const int ttail = tail_ok ? (NSTEP - 1) * 64 + lane : 0;
+        const int last = w.v_hi - 1;
+        int vi = w.v_lo + wave;
+        if (vi <= last) {
+            // taps + value of one visibility -> registers (NSTEP+1 vector loads, nothing waited on here)
+            auto issue = [&](const VisRec &r, double2 &v, double2(&k)[NSTEP]) {
+                const double2 *kp = gcf + (size_t)(DBG >= 2 ? 0 : r.kslice) * S2;
+                v = vis[r.orig];
+#pragma unroll
+                for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lane];
+                k[NSTEP - 1] = kp[ttail];
+            };
+            auto add = [&](int a, double re, double im) {
+                if (DBG == 1 || DBG == 3) {
+                    if (re == 12345.678 && im == 9.0) lre[a] = re;  // keeps loads + multiply alive
+                } else {
+                    __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            };
+            auto accum = [&](const VisRec &r, const double2 &v, const double2(&k)[NSTEP]) {
+                const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    double re = v.x * k[s].x - v.y * k[s].y;
+                    double im = v.x * k[s].y + v.y * k[s].x;
+                    if (s == NSTEP - 1 && TAIL != 64) {
+                        re = tail_ok ? re : 0.0;
+                        im = tail_ok ? im : 0.0;
+                    }
+                    add(lbase + loff[s], re, im);
+                }
+            };
+            // Two register sets (A, B) used alternately so no tap register is ever copied (a copy
+            // would have to wait for the loads just issued).  Two visibilities per trip and no
+            // exit between a prefetch and its use: LLVM otherwise sinks the loads past the exit
+            // test and the pipeline collapses.  The odd one out at the end is a repeat of the
+            // last visibility with its value forced to zero (adds 0.0 to the same cells).
+            double2 kA[NSTEP], kB[NSTEP], valA, valB;
+            VisRec r0 = load_rec(recs, vi);                   // visibility t
+            VisRec r1 = load_rec(recs, min(vi + nw, last));   // t+1
+            issue(r0, valA, kA);
+            for (; vi <= last; vi += 2 * nw) {
+                const VisRec r2 = load_rec(recs, min(vi + 2 * nw, last));  // t+2
+                issue(r1, valB, kB);
+                __builtin_amdgcn_sched_barrier(0);
+                accum(r0, valA, kA);
+                __builtin_amdgcn_sched_barrier(0);
+                const VisRec r3 = load_rec(recs, min(vi + 3 * nw, last));  // t+3
+                issue(r2, valA, kA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (vi + nw > last) valB = make_double2(0.0, 0.0);
+                accum(r1, valB, kB);
+                __builtin_amdgcn_sched_barrier(0);
+                r0 = r2;
+                r1 = r3;
+            }
+        }
+    } else {
+        const int dj = 64 % gw, di = 64 / gw;
+        for (int vi = w.v_lo + wave; vi < w.v_hi; vi += nw) {
+            const VisRec r = load_rec(recs, vi);
+            const double2 val = vis[r.orig];
+            const double2 *kp = gcf + (size_t)r.kslice * S2;
+            const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);
+            int i = lane / gw, j = lane - i * gw;
+            for (int t = lane; t < S2; t += 64) {
+                const double2 kv = kp[t];
+                const double re = val.x * kv.x - val.y * kv.y;
+                const double im = val.x * kv.y + val.y * kv.x;
+                const int a = lbase + i * g.ldw + j;
                 __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                j += dj;
+                i += di;
+                if (j >= gw) {
+                    j -= gw;
+                    ++i;
+                }
             }
         }
     }
@@ -126,7 +217,6 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
 
 // Gather twin: vis_out[orig] = sum_ij gcf[kslice][i][j] * G[y0+i][x0+j]; the tile (zero outside
 // the grid) is staged in LDS once per work item, taps are summed across the wave.
-template <int RW>
 __global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec *__restrict__ recs,
                                                            const int32_t *__restrict__ bin_start,
                                                            const int32_t *__restrict__ work_start,
@@ -154,26 +244,29 @@ __global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec 
     }
     __syncthreads();
 
-    constexpr int RPI = 64 / RW;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = tid >> 6;
     const int nw = blockDim.x >> 6;
-    const int j = lane % RW, ri = lane / RW;
-    const bool jok = j < g.gw;
-    const int S2 = g.gh * g.gw;
+    const int gw = g.gw, S2 = g.gh * g.gw;
+    const int dj = 64 % gw, di = 64 / gw;
 
     for (int vi = w.v_lo + wave; vi < w.v_hi; vi += nw) {
-        const VisRec r = load_rec(recs, __builtin_amdgcn_readfirstlane(vi));
-        const double2 *kp = gcf + (size_t)r.kslice * S2 + j;
-        const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff) + j;
+        const VisRec r = load_rec(recs, vi);
+        const double2 *kp = gcf + (size_t)r.kslice * S2;
+        const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);
         double sr = 0.0, si = 0.0;
-        for (int i = ri; i < g.gh; i += RPI) {
-            if (jok) {
-                const double2 kv = kp[i * g.gw];
-                const int a = lbase + i * g.ldw;
-                const double gr = lre[a], gi = lim[a];
-                sr += kv.x * gr - kv.y * gi;
-                si += kv.x * gi + kv.y * gr;
+        int i = lane / gw, j = lane - i * gw;
+        for (int t = lane; t < S2; t += 64) {
+            const double2 kv = kp[t];
+            const int a = lbase + i * g.ldw + j;
+            const double gr = lre[a], gi = lim[a];
+            sr += kv.x * gr - kv.y * gi;
+            si += kv.x * gi + kv.y * gr;
+            j += dj;
+            i += di;
+            if (j >= gw) {
+                j -= gw;
+                ++i;
             }
         }
 #pragma unroll
@@ -203,26 +296,30 @@ static int work_blocks(const Geom &g, int64_t n)
 }
 
 int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int64_t n,
-                     const double *gcf, double *grid)
+                     const double *gcf, const double *vis, double *grid)
 {
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
-#define GH_LAUNCH(RW_, BIT_)                                                                              \
-    case RW_:                                                                                             \
-        GH_CHECK(raise_lds(ctx, tile_grid_kernel<RW_>, BIT_));                                            \
-        hipLaunchKernelGGL(tile_grid_kernel<RW_>, gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start,   \
-                           t.work_start, (const double2 *)gcf, grid);                                     \
-        break;
-    switch (g.rw) {
-        GH_LAUNCH(2, 1u << 4)
-        GH_LAUNCH(4, 1u << 5)
-        GH_LAUNCH(8, 1u << 6)
-        GH_LAUNCH(16, 1u << 7)
-        GH_LAUNCH(32, 1u << 8)
-        GH_LAUNCH(64, 1u << 9)
-        default: return fail(ctx, GRIDHIP_EUNSUPPORTED, "kernel width %d", g.gw);
-    }
+#define GH_LAUNCH(S_, D_, BIT_)                                                                             \
+    do {                                                                                                    \
+        GH_CHECK(raise_lds(ctx, tile_grid_kernel<S_, D_>, BIT_));                                           \
+        hipLaunchKernelGGL((tile_grid_kernel<S_, D_>), gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start, \
+                           t.work_start, (const double2 *)gcf, (const double2 *)vis, grid);                 \
+    } while (0)
+    if (g.gh == 15 && g.gw == 15) {
+        if (g.dbg == 1)
+            GH_LAUNCH(15, 1, 1u << 16);
+        else if (g.dbg == 2)
+            GH_LAUNCH(15, 2, 1u << 17);
+        else if (g.dbg == 3)
+            GH_LAUNCH(15, 3, 1u << 18);
+        else
+            GH_LAUNCH(15, 0, 1u << 2);
+    } else if (g.gh == 7 && g.gw == 7)
+        GH_LAUNCH(7, 0, 1u << 3);
+    else
+        GH_LAUNCH(0, 0, 1u << 4);
 #undef GH_LAUNCH
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
@@ -234,22 +331,9 @@ int launch_tile_degrid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_by
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
-#define GH_LAUNCH(RW_, BIT_)                                                                               \
-    case RW_:                                                                                              \
-        GH_CHECK(raise_lds(ctx, tile_degrid_kernel<RW_>, BIT_));                                           \
-        hipLaunchKernelGGL(tile_degrid_kernel<RW_>, gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start,  \
-                           t.work_start, (const double2 *)gcf, (const double2 *)grid, (double2 *)vis_out); \
-        break;
-    switch (g.rw) {
-        GH_LAUNCH(2, 1u << 10)
-        GH_LAUNCH(4, 1u << 11)
-        GH_LAUNCH(8, 1u << 12)
-        GH_LAUNCH(16, 1u << 13)
-        GH_LAUNCH(32, 1u << 14)
-        GH_LAUNCH(64, 1u << 15)
-        default: return fail(ctx, GRIDHIP_EUNSUPPORTED, "kernel width %d", g.gw);
-    }
-#undef GH_LAUNCH
+    GH_CHECK(raise_lds(ctx, tile_degrid_kernel, 1u << 10));
+    hipLaunchKernelGGL(tile_degrid_kernel, gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start, t.work_start,
+                       (const double2 *)gcf, (const double2 *)grid, (double2 *)vis_out);
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }
