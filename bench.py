@@ -125,7 +125,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="gridhip option key=value (tile, block, chunk, wgroups, variant, sort)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per tile-kernel launch from a separate rocprofv3 --pmc pass")
+                    help="HBM bytes per tile-kernel launch from a separate rocprofv3 --pmc pass "
+                         "(default: the committed measurement in profiles/traffic.json for this workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,6 +186,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    traffic = args.traffic_bytes
+    if traffic is None and not args.opt and not args.nvis and args.dist == "uniform":
+        # PMC counters cannot be collected inside this run; quote the committed rocprofv3 --pmc
+        # measurement of the same workload (tools/profile.sh -> profiles/traffic.json)
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_vis = n * world
@@ -216,7 +225,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": args.traffic_bytes,
+                "traffic": traffic,
                 "alg_bytes_per_vis": alg_bytes_per_vis(S),
                 "kernel_ms_avg": k_avg,
                 "prepass_ms_avg": float(np.mean(pre_ms)),
