@@ -155,12 +155,13 @@ def main():
     gcf = synth_kernels(W, Q, S, device)
     u, v, wb, vis = synth_vis(n, N, W, S, 0x5EEDC0DE + rank, device, dist=args.dist)
     G = torch.zeros((N, N), dtype=torch.complex128, device=device)
-    Gr = torch.view_as_real(G)
+    from gridhip.distributed import allreduce_grid
 
     def step():
+        # this rank's shard of the stream (generated per rank: shard r of a world*n stream)
         ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
         if dist is not None:
-            dist.all_reduce(Gr)  # fp64 sum of the partial grids over xGMI (RCCL)
+            allreduce_grid(G)  # one fp64 sum all-reduce of the partial grids over xGMI (RCCL)
 
     ctx.enable_timing(True)
     for _ in range(args.warmup):
