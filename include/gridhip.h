@@ -118,6 +118,49 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
                         const double *gcf, const double *u, const double *v,
                         int64_t uv_stride, const int64_t *wbin, double *vis_out);
 
+/* ---- callers either side of the gridder (host pointers) -------------------------
+ * All follow src/Gridding.hs; uvw are in wavelengths where the reference takes them so. */
+
+/* N = round (theta * lam) as the imaging functions compute it (:87,:118,:416; Prelude round). */
+int64_t gridhip_image_size(double theta, int64_t lam);
+/* w-bin rule of w_cache_imaging, :426-432: wbin = (wstep*round(w/wstep) - min) div wstep. */
+int gridhip_wbins(gridhip_ctx *ctx, int64_t n, const double *w, int64_t wstep, int64_t *wbin,
+                  int64_t *wmin, int64_t *nplanes);
+/* findClosest, :895-907, for each w (out of range reads clamped as ImageDataset.hs:150-168). */
+int gridhip_find_closest(gridhip_ctx *ctx, int64_t nws, const double *ws, int64_t n,
+                         const double *w, int64_t *out);
+/* mirror_uvw, :551-562, in place (w and vis may be NULL). */
+int gridhip_mirror_uvw(gridhip_ctx *ctx, int64_t n, double *u, double *v, double *w, double *vis);
+/* doweight, :564-583: vis /= number of visibilities in its grid cell; u, v in wavelengths. */
+int gridhip_doweight(gridhip_ctx *ctx, double theta, int64_t lam, int64_t n, const double *u,
+                     const double *v, double *vis);
+/* make_grid_hermitian, :585-605, in place. */
+int gridhip_make_grid_hermitian(gridhip_ctx *ctx, int64_t N, double *grid);
+/* fft / ifft, :815-829: shift2D . fft2D . ishift2D on an N x N complex array (hipFFT);
+ * inverse != 0 is scaled by 1/N^2 as accelerate-fft's Inverse mode. */
+int gridhip_fft2_centered(gridhip_ctx *ctx, int64_t N, const double *in, double *out, int inverse);
+/* w_kernel, :610-728: out is [qpx][qpx][npixKern][npixKern]. */
+int gridhip_w_kernel(gridhip_ctx *ctx, double theta, double w, int64_t npixFF, int64_t npixKern,
+                     int64_t qpx, double *out);
+/* ImagingFunctions (:76-81): grid is N x N with N = gridhip_image_size(theta, lam), overwritten. */
+int gridhip_simple_imaging(gridhip_ctx *ctx, double theta, int64_t lam, int64_t n, const double *u,
+                           const double *v, int64_t uv_stride, const double *vis, double *grid);
+int gridhip_conv_imaging(gridhip_ctx *ctx, int64_t Q, int64_t gh, int64_t gw, const double *kv,
+                         double theta, int64_t lam, int64_t n, const double *u, const double *v,
+                         int64_t uv_stride, const double *vis, double *grid);
+/* w_cache_imaging, :399-449: builds one conjugated w_kernel per plane, then convgrid2. */
+int gridhip_w_cache_imaging(gridhip_ctx *ctx, int64_t wstep, int64_t qpx, int64_t npixFF,
+                            int64_t npixKern, double theta, int64_t lam, int64_t n, const double *u,
+                            const double *v, const double *w, int64_t uv_stride, const double *vis,
+                            double *grid);
+/* do_imaging, :509-549: mirror -> weight -> grid(vis*wt), grid(wt) -> hermitian -> ifft -> /max(psf).
+ * kind: 0 simple_imaging; 1 conv_imaging (Q, gh, gw, kv); 2 w_cache_imaging (wstep, Q, npixFF, gh = npixKern).
+ * image and psf are N x N doubles. */
+int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int64_t npixFF,
+                       int64_t gh, int64_t gw, const double *kv, double theta, int64_t lam, int64_t n,
+                       const double *u, const double *v, const double *w, int64_t uv_stride,
+                       const double *vis, double *image, double *psf, double *pmax);
+
 /* ---- device memory helpers (so a non-HIP host language can stage buffers) ----------------- */
 int gridhip_malloc(gridhip_ctx *ctx, void **dptr, int64_t bytes);
 int gridhip_free(gridhip_ctx *ctx, void *dptr);

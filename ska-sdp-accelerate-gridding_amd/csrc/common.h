@@ -68,6 +68,8 @@ struct gridhip_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     uint32_t attr_mask = 0;  // which kernels already had their dynamic-LDS limit raised
+    void *fft_plan = nullptr;  // cached hipFFT Z2Z plan (imaging.hip)
+    int64_t fft_n = 0;
 };
 
 namespace gridhip {
@@ -144,6 +146,7 @@ struct Tables {
     int32_t *cursor;      // [nbins] scatter cursors
     int32_t *scalars;     // = ctx->d_scalars
 };
+void fft_release(gridhip_ctx *ctx);
 Tables tables_of(gridhip_ctx *ctx, const Geom &g);
 size_t tables_bytes(const Geom &g);
 

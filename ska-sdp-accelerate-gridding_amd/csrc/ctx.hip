@@ -225,6 +225,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     if (!ctx) return GRIDHIP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    fft_release(ctx);
     Workspace *all[] = {&ctx->recs, &ctx->keys, &ctx->tables, &ctx->stage};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);

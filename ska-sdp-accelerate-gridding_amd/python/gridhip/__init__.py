@@ -191,6 +191,135 @@ class Context:
         return out
 
 
+    # -- callers either side of the gridder (host arrays; src/Gridding.hs names) -----------------
+    def image_size(self, theta, lam):
+        return int(self._lib.gridhip_image_size(float(theta), int(lam)))
+
+    def wbins(self, w, wstep):
+        """w-bin rule of w_cache_imaging (:426-432) -> (wbin, wmin, nplanes)"""
+        w = self._np(w, np.float64)
+        out = np.empty(len(w), dtype=np.int64)
+        mn, npl = C.c_int64(), C.c_int64()
+        self._check(self._lib.gridhip_wbins(self._h, len(w), self._ptr(w), int(wstep), self._ptr(out), C.byref(mn),
+                                            C.byref(npl)))
+        return out, mn.value, npl.value
+
+    def findClosest(self, ws, w):
+        """:895-907, vectorised over w"""
+        ws, w = self._np(ws, np.float64), self._np(np.atleast_1d(w), np.float64)
+        out = np.empty(len(w), dtype=np.int64)
+        self._check(self._lib.gridhip_find_closest(self._h, len(ws), self._ptr(ws), len(w), self._ptr(w),
+                                                   self._ptr(out)))
+        return out
+
+    def mirror_uvw(self, uvw, vis):
+        """:551-562 -> ((u, v, w), vis)"""
+        u, v, w = (self._np(x, np.float64).copy() for x in uvw)
+        vis = self._np(vis, np.complex128).copy()
+        self._check(self._lib.gridhip_mirror_uvw(self._h, len(u), self._ptr(u), self._ptr(v), self._ptr(w),
+                                                 self._ptr(vis)))
+        return (u, v, w), vis
+
+    def doweight(self, theta, lam, p, v):
+        """:564-583 ; p in wavelengths"""
+        u, vv = self._np(p[0], np.float64), self._np(p[1], np.float64)
+        vis = self._np(v, np.complex128).copy()
+        self._check(self._lib.gridhip_doweight(self._h, float(theta), int(lam), len(u), self._ptr(u), self._ptr(vv),
+                                               self._ptr(vis)))
+        return vis
+
+    def make_grid_hermitian(self, guv):
+        """:585-605"""
+        g = self._np(guv, np.complex128).copy()
+        self._check(self._lib.gridhip_make_grid_hermitian(self._h, g.shape[0], self._ptr(g)))
+        return g
+
+    def _fft(self, m, inverse):
+        m = self._np(m, np.complex128)
+        out = np.empty_like(m)
+        self._check(self._lib.gridhip_fft2_centered(self._h, m.shape[0], self._ptr(m), self._ptr(out), int(inverse)))
+        return out
+
+    def ifft(self, m):
+        """:828-829"""
+        return self._fft(m, True)
+
+    def fft(self, m):
+        """:815-816 (fftO)"""
+        return self._fft(m, False)
+
+    def w_kernel(self, theta, w, npixFF, npixKern, qpx):
+        """:610-619 -> [qpx, qpx, npixKern, npixKern]"""
+        out = np.empty((qpx, qpx, npixKern, npixKern), dtype=np.complex128)
+        self._check(self._lib.gridhip_w_kernel(self._h, float(theta), float(w), int(npixFF), int(npixKern), int(qpx),
+                                               self._ptr(out)))
+        return out
+
+    def _uvw(self, uvw):
+        if isinstance(uvw, (tuple, list)):
+            u, v, w = (self._np(x, np.float64) for x in uvw)
+            return u, v, w, 1
+        m = self._np(uvw, np.float64)
+        return m[:, 0], m[:, 1], m[:, 2], 3
+
+    def simple_imaging(self, theta, lam, uvw, src, vis):
+        """:84-93 (src is unused by this imaging function, as in the reference)"""
+        u, v, _, st = self._uvw(uvw)
+        vis = self._np(vis, np.complex128)
+        N = self.image_size(theta, lam)
+        g = np.empty((N, N), dtype=np.complex128)
+        self._check(self._lib.gridhip_simple_imaging(self._h, float(theta), int(lam), len(vis), self._ptr(u),
+                                                     self._ptr(v), st, self._ptr(vis), self._ptr(g)))
+        return g
+
+    def conv_imaging(self, kv, theta, lam, uvw, src, vis):
+        """:115-124 ; kv [Q,Q,gh,gw]"""
+        u, v, _, st = self._uvw(uvw)
+        vis, kv = self._np(vis, np.complex128), self._np(kv, np.complex128)
+        Q, _, gh, gw = kv.shape
+        N = self.image_size(theta, lam)
+        g = np.empty((N, N), dtype=np.complex128)
+        self._check(self._lib.gridhip_conv_imaging(self._h, Q, gh, gw, self._ptr(kv), float(theta), int(lam), len(vis),
+                                                   self._ptr(u), self._ptr(v), st, self._ptr(vis), self._ptr(g)))
+        return g
+
+    def w_cache_imaging(self, kernops, theta, lam, uvw, src, vis):
+        """:399-449 ; kernops = dict(wstep=, qpx=, npixFF=, npixKern=) as KernelOptions (:30-38)"""
+        u, v, w, st = self._uvw(uvw)
+        vis = self._np(vis, np.complex128)
+        N = self.image_size(theta, lam)
+        g = np.empty((N, N), dtype=np.complex128)
+        self._check(self._lib.gridhip_w_cache_imaging(
+            self._h, int(kernops.get("wstep") or 2000), int(kernops["qpx"]), int(kernops["npixFF"]),
+            int(kernops["npixKern"]), float(theta), int(lam), len(vis), self._ptr(u), self._ptr(v), self._ptr(w), st,
+            self._ptr(vis), self._ptr(g)))
+        return g
+
+    def do_imaging(self, theta, lam, uvw, a1, a2, t, f, vis, imgfn):
+        """:509-549 -> (image, psf, pmax).  imgfn = ("simple",) | ("conv", kv) | ("w_cache", kernops);
+        a1, a2, t, f (src) are accepted for signature parity and unused by these imaging functions."""
+        u, v, w, st = self._uvw(uvw)
+        vis = self._np(vis, np.complex128)
+        N = self.image_size(theta, lam)
+        img = np.empty((N, N), dtype=np.float64)
+        psf = np.empty((N, N), dtype=np.float64)
+        pmax = C.c_double()
+        kind, wstep, Q, npixFF, gh, gw, kv = 0, 0, 0, 0, 0, 0, None
+        if imgfn[0] == "conv":
+            kv = self._np(imgfn[1], np.complex128)
+            kind, (Q, _, gh, gw) = 1, kv.shape
+        elif imgfn[0] == "w_cache":
+            ko = imgfn[1]
+            kind, wstep, Q, npixFF, gh = 2, int(ko.get("wstep") or 2000), int(ko["qpx"]), int(ko["npixFF"]), int(ko["npixKern"])
+            gw = gh
+        elif imgfn[0] != "simple":
+            raise ValueError("unknown imaging function")
+        self._check(self._lib.gridhip_do_imaging(self._h, kind, wstep, Q, npixFF, gh, gw, self._ptr(kv), float(theta),
+                                                 int(lam), len(vis), self._ptr(u), self._ptr(v), self._ptr(w), st,
+                                                 self._ptr(vis), self._ptr(img), self._ptr(psf), C.byref(pmax)))
+        return img, psf, pmax.value
+
+
 _default = {}
 
 

@@ -42,6 +42,19 @@ SIGNATURES = {
     "gridhip_convgrid_dev": (ci, _CONV_DEV),
     "gridhip_convgrid2_dev": (ci, _CONV2_DEV),
     "gridhip_degrid2_dev": (ci, _CONV2_DEV),
+    "gridhip_image_size": (i64, [C.c_double, i64]),
+    "gridhip_wbins": (ci, [vp, i64, vp, i64, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "gridhip_find_closest": (ci, [vp, i64, vp, i64, vp, vp]),
+    "gridhip_mirror_uvw": (ci, [vp, i64, vp, vp, vp, vp]),
+    "gridhip_doweight": (ci, [vp, C.c_double, i64, i64, vp, vp, vp]),
+    "gridhip_make_grid_hermitian": (ci, [vp, i64, vp]),
+    "gridhip_fft2_centered": (ci, [vp, i64, vp, vp, ci]),
+    "gridhip_w_kernel": (ci, [vp, C.c_double, C.c_double, i64, i64, i64, vp]),
+    "gridhip_simple_imaging": (ci, [vp, C.c_double, i64, i64, vp, vp, i64, vp, vp]),
+    "gridhip_conv_imaging": (ci, [vp, i64, i64, i64, vp, C.c_double, i64, i64, vp, vp, i64, vp, vp]),
+    "gridhip_w_cache_imaging": (ci, [vp, i64, i64, i64, i64, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp]),
+    "gridhip_do_imaging": (ci, [vp, ci, i64, i64, i64, i64, i64, vp, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp,
+                                vp, C.POINTER(C.c_double)]),
     "gridhip_malloc": (ci, [vp, C.POINTER(vp), i64]),
     "gridhip_free": (ci, [vp, vp]),
     "gridhip_memcpy_h2d": (ci, [vp, vp, vp, i64]),
