@@ -153,6 +153,24 @@ int gridhip_w_cache_imaging(gridhip_ctx *ctx, int64_t wstep, int64_t qpx, int64_
                             int64_t npixKern, double theta, int64_t lam, int64_t n, const double *u,
                             const double *v, const double *w, int64_t uv_stride, const double *vis,
                             double *grid);
+/* convgrid3 / convgrid4, :246-396 (both produce this grid): per visibility
+ * awkern = conj(aw_kernel_fn2 yf xf wkerns[wbin] akerns[a1] akerns[a2]) (:761-775, convolve2d :795-811 with
+ * its transposing pad), G[y0+i,x0+j] += vis*awkern[i,j].  wkerns [W][Q][Q][S][S], akerns [A][S][S];
+ * the index triple (wbin, a1, a2) is passed as three arrays (Accelerate's struct-of-arrays). */
+int gridhip_awgrid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W,
+                   int64_t Q, int64_t S, int64_t A, const double *wkerns, const double *akerns,
+                   const double *u, const double *v, int64_t uv_stride, const int64_t *wbin,
+                   const int64_t *a1, const int64_t *a2, const double *vis);
+int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W,
+                       int64_t Q, int64_t S, int64_t A, const double *wkerns, const double *akerns,
+                       const double *u, const double *v, int64_t uv_stride, const int64_t *wbin,
+                       const int64_t *a1, const int64_t *a2, const double *vis);
+/* aw_imaging / aw_imagingOld, :452-506: wvals are the W plane w-values searched by findClosest. */
+int gridhip_aw_imaging(gridhip_ctx *ctx, double theta, int64_t lam, int64_t W, int64_t Q, int64_t S,
+                       int64_t A, const double *wkerns, const double *wvals, const double *akerns,
+                       int64_t n, const double *u, const double *v, const double *w,
+                       int64_t uv_stride, const int64_t *a1, const int64_t *a2, const double *vis,
+                       double *grid);
 /* do_imaging, :509-549: mirror -> weight -> grid(vis*wt), grid(wt) -> hermitian -> ifft -> /max(psf).
  * kind: 0 simple_imaging; 1 conv_imaging (Q, gh, gw, kv); 2 w_cache_imaging (wstep, Q, npixFF, gh = npixKern).
  * image and psf are N x N doubles. */

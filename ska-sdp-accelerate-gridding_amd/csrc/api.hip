@@ -133,6 +133,33 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     return GRIDHIP_OK;
 }
 
+}  // extern "C"
+
+namespace gridhip {
+// convgrid with one private kernel slice per visibility (the aw gridders, awgrid.hip)
+int grid_per_vis_kernels(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t Q, int64_t gh,
+                         int64_t gw, const double *kperv, const double *u, const double *v, int64_t uv_stride,
+                         const double *vis)
+{
+    Geom g;
+    int block;
+    size_t lds;
+    const int64_t keep = ctx->opt.wgroups;
+    ctx->opt.wgroups = 1;  // every slice is used once: nothing for an L2 to keep
+    int rc = make_geom(ctx, H, Wd, 1, Q, gh, gw, n, &g, &block, &lds);
+    ctx->opt.wgroups = keep;
+    GH_CHECK(rc);
+    g.per_vis = 1;
+    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
+    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, nullptr));
+    if (n > 0) GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, kperv, vis, grid));
+    return GRIDHIP_OK;
+}
+}  // namespace gridhip
+
+extern "C" {
+
 // ---------------------------------------------------------------------------------------------
 // host-pointer forms
 

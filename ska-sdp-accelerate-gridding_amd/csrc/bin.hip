@@ -17,7 +17,7 @@ struct BinOut {
     int32_t lxy, kslice;
 };
 
-__device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, int64_t wb)
+__device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, int64_t wb, int64_t k)
 {
     BinOut o;
     int64_t x, y;
@@ -45,7 +45,7 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
     const int32_t grp = ((int32_t)wb * g.ngroups) / g.W;  // 32-bit: W * ngroups < 2^31
     o.bin = grp * g.ntiles + ty * g.ntx + tx;
     o.lxy = (ly << 16) | lx;
-    o.kslice = ((int32_t)wb * g.Q + yf) * g.Q + xf;
+    o.kslice = g.per_vis ? (int32_t)k : ((int32_t)wb * g.Q + yf) * g.Q + xf;
     return o;
 }
 
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
     block_range(n, &lo, &hi);
     int dropped = 0;
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0);
+        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
         if (b.bin >= 0) {
             if (LDS_HIST)
                 atomicAdd(&hist[b.bin], 1);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
         __syncthreads();
         // sweep 1: how many of this block's visibilities go to each bin
         for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-            BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0);
+            BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
             if (b.bin >= 0) atomicAdd(&hist[b.bin], 1);
         }
         __syncthreads();
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
     }
     // sweep 2: write the records
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0);
+        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
         if (b.bin < 0) continue;
         int slot;
         if (LDS_HIST)

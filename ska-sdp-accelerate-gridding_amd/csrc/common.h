@@ -37,6 +37,7 @@ struct Geom {
     int32_t lrows, lcols; // valid LDS region: T+gh-1 rows, T+gw-1 columns
     int32_t chunk;        // max visibilities per work item
     int32_t dbg;          // ablation switch for tuning runs (0 = off)
+    int32_t per_vis;      // 1: the kernel table holds one [gh][gw] slice per visibility (aw gridders)
 };
 
 struct Options {
@@ -98,6 +99,10 @@ int ws_reserve(gridhip_ctx *ctx, Workspace &ws, size_t bytes);
 // geometry / option resolution (host)
 int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh,
               int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes);
+// grids n visibilities whose kernels are kperv[k][gh][gw] (device pointers, stream-ordered)
+int grid_per_vis_kernels(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t Q,
+                         int64_t gh, int64_t gw, const double *kperv, const double *u, const double *v,
+                         int64_t uv_stride, const double *vis);
 
 // ---- device-side coordinate math ---------------------------------------------------------
 // frac_coord of src/Gridding.hs:126-140, bit-for-bit with the oracle: contraction is switched

@@ -831,6 +831,54 @@ int gridhip_w_cache_imaging(gridhip_ctx *ctx, int64_t wstep, int64_t qpx, int64_
     return sync(ctx);
 }
 
+// aw_imaging / aw_imagingOld, src/Gridding.hs:452-506: p = uvw/lam, wbin = findClosest wbins w,
+// index = (wbin, a1, a2), then convgrid4 / convgrid3 (same grid).  wvals are the W plane w-values.
+int gridhip_aw_imaging(gridhip_ctx *ctx, double theta, int64_t lam, int64_t W, int64_t Q, int64_t S, int64_t A,
+                       const double *wkerns, const double *wvals, const double *akerns, int64_t n, const double *u,
+                       const double *v, const double *w, int64_t uv_stride, const int64_t *a1, const int64_t *a2,
+                       const double *vis, double *grid)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    const int64_t N = haskell_round(theta * (double)lam);
+    if (N <= 0 || n < 0 || uv_stride < 1 || W <= 0 || Q <= 0 || S <= 0 || A <= 0 || !grid || !wkerns || !wvals ||
+        !akerns || (n > 0 && (!u || !v || !w || !a1 || !a2 || !vis)))
+        return fail(ctx, GRIDHIP_EINVAL, "bad argument");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf du, dv, dw, dvis, dg, dpu, dpv, dwb, dws, da1, da2, dwk, dak;
+    GH_CHECK(stage3(ctx, n, u, v, w, uv_stride, vis, du, dv, dw, dvis));
+    const size_t wel = (size_t)W * Q * Q * S * S, ael = (size_t)A * S * S;
+    GH_CHECK(dg.alloc(ctx, (size_t)N * N * 16));
+    GH_CHECK(dpu.alloc(ctx, n * 8));
+    GH_CHECK(dpv.alloc(ctx, n * 8));
+    GH_CHECK(dwb.alloc(ctx, n * 8));
+    GH_CHECK(dws.alloc(ctx, W * 8));
+    GH_CHECK(da1.alloc(ctx, n * 8));
+    GH_CHECK(da2.alloc(ctx, n * 8));
+    GH_CHECK(dwk.alloc(ctx, wel * 16));
+    GH_CHECK(dak.alloc(ctx, ael * 16));
+    GH_CHECK(h2d(ctx, dws.p, wvals, W * 8));
+    GH_CHECK(h2d(ctx, da1.p, a1, n * 8));
+    GH_CHECK(h2d(ctx, da2.p, a2, n * 8));
+    GH_CHECK(h2d(ctx, dwk.p, wkerns, wel * 16));
+    GH_CHECK(h2d(ctx, dak.p, akerns, ael * 16));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(dg.p, 0, (size_t)N * N * 16, ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, du.as<double>(), (int64_t)1,
+                           (double)lam, dpu.as<double>());
+        hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, dv.as<double>(), (int64_t)1,
+                           (double)lam, dpv.as<double>());
+        // NB the reference searches with w in wavelengths, not w/lam (:473-474)
+        hipLaunchKernelGGL(find_closest_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, W, dws.as<double>(), n,
+                           dw.as<double>(), (int64_t)1, dwb.as<int64_t>());
+    }
+    GH_CHECK_HIP(ctx, hipGetLastError());
+    GH_CHECK(gridhip_awgrid_dev(ctx, N, N, dg.as<double>(), n, W, Q, S, A, dwk.as<double>(), dak.as<double>(),
+                                dpu.as<double>(), dpv.as<double>(), 1, dwb.as<int64_t>(), da1.as<int64_t>(),
+                                da2.as<int64_t>(), dvis.as<double>()));
+    GH_CHECK(d2h(ctx, grid, dg.p, (size_t)N * N * 16));
+    return sync(ctx);
+}
+
 // do_imaging, src/Gridding.hs:509-549.  kind selects the ImagingFunction:
 //   0 simple_imaging ; 1 conv_imaging kv (Q, gh, gw, kv) ; 2 w_cache_imaging (wstep, Q=qpx, npixFF, gh=npixKern)
 int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int64_t npixFF, int64_t gh, int64_t gw,

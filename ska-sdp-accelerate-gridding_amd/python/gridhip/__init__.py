@@ -191,6 +191,45 @@ class Context:
         return out
 
 
+    def convgrid4(self, wkerns, akerns, a, p, index, v):
+        """src/Gridding.hs:318-396 ; index = (wbin, a1, a2) arrays.  convgrid3 (:246-317) gives the same grid."""
+        wbin, a1, a2 = index
+        dev, a, pu, pv, stride, vis, wbin, wkerns = self._prep(a, p, v, wbin, wkerns)
+        W, Q, _, S, _ = wkerns.shape
+        n = int(pu.shape[0])
+        if dev:
+            import torch
+            cv = lambda t, dt: t if (t.dtype == dt and t.is_contiguous()) else t.to(dt).contiguous()
+            akerns, a1, a2 = cv(akerns, torch.complex128), cv(a1, torch.int64), cv(a2, torch.int64)
+            fn = self._lib.gridhip_awgrid_dev
+        else:
+            akerns, a1, a2 = self._np(akerns, np.complex128), self._np(a1, np.int64), self._np(a2, np.int64)
+            fn = self._lib.gridhip_awgrid
+        self._check(fn(self._h, a.shape[0], a.shape[1], self._ptr(a), n, W, Q, S, akerns.shape[0], self._ptr(wkerns),
+                       self._ptr(akerns), self._ptr(pu), self._ptr(pv), stride, self._ptr(wbin), self._ptr(a1),
+                       self._ptr(a2), self._ptr(vis)))
+        return a
+
+    convgrid3 = convgrid4
+
+    def aw_imaging(self, theta, lam, wkernels, wbins, akernels, uvw, src, vis):
+        """src/Gridding.hs:452-478 (aw_imagingOld :480-506 gives the same grid); src = (a1, a2, t, f)"""
+        u, v, w, st = self._uvw(uvw)
+        vis = self._np(vis, np.complex128)
+        wk, ak = self._np(wkernels, np.complex128), self._np(akernels, np.complex128)
+        wv = self._np(wbins, np.float64)
+        a1, a2 = self._np(src[0], np.int64), self._np(src[1], np.int64)
+        W, Q, _, S, _ = wk.shape
+        N = self.image_size(theta, lam)
+        g = np.empty((N, N), dtype=np.complex128)
+        self._check(self._lib.gridhip_aw_imaging(self._h, float(theta), int(lam), W, Q, S, ak.shape[0], self._ptr(wk),
+                                                 self._ptr(wv), self._ptr(ak), len(vis), self._ptr(u), self._ptr(v),
+                                                 self._ptr(w), st, self._ptr(a1), self._ptr(a2), self._ptr(vis),
+                                                 self._ptr(g)))
+        return g
+
+    aw_imagingOld = aw_imaging
+
     # -- callers either side of the gridder (host arrays; src/Gridding.hs names) -----------------
     def image_size(self, theta, lam):
         return int(self._lib.gridhip_image_size(float(theta), int(lam)))
