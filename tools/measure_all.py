@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Measure the secondary configurations on one GPU (the headline number comes from bench.py):
+cfg2 grid, cfg3 grid with the 'core' distribution, cfg3 degrid, cfg4 aw-gridding.  Prints one
+JSON line per measurement; timings are HIP-event totals (pre-pass + kernel) or wall time."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "python"))
+import numpy as np
+import torch
+import bench
+import gridhip
+
+dev = torch.device("cuda:0")
+ctx = gridhip.Context(0)
+ctx.enable_timing(True)
+
+
+def timed(fn, reps=3):
+    fn()
+    ts = []
+    for _ in range(reps):
+        fn()
+        ts.append(ctx.last_timing())
+    return np.array(ts).min(axis=0)
+
+
+def wall(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3
+
+
+def report(name, n, t_ms, extra=None):
+    d = {"what": name, "n": n, "ms": round(float(t_ms), 3), "Mvis_per_s": round(n / float(t_ms) / 1e3, 1)}
+    d.update(extra or {})
+    print(json.dumps(d), flush=True)
+
+
+which = sys.argv[1:] or ["cfg2", "core", "degrid", "aw"]
+if "cfg2" in which:
+    n, N, W, Q, S = bench.WORKLOADS["cfg2"]
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    u, v, wb, vis = bench.synth_vis(n, N, W, S, 1, dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    t = timed(lambda: ctx.convgrid2(gcf, G, (u, v, None), wb, vis), 5)
+    report("cfg2 grid: 1e6 vis, 2048^2, 7x7, 16 planes", n, t[0], {"prepass_ms": round(float(t[1]), 3), "kernel_ms": round(float(t[2]), 3)})
+    del gcf, u, v, wb, vis, G
+if "core" in which or "degrid" in which:
+    n, N, W, Q, S = bench.WORKLOADS["cfg3"]
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    if "core" in which:
+        u, v, wb, vis = bench.synth_vis(n, N, W, S, 2, dev, dist="core")
+        t = timed(lambda: ctx.convgrid2(gcf, G, (u, v, None), wb, vis))
+        report("cfg3 grid, centrally concentrated uv (distribution B)", n, t[0], {"prepass_ms": round(float(t[1]), 3), "kernel_ms": round(float(t[2]), 3)})
+        del u, v, wb, vis
+    if "degrid" in which:
+        u, v, wb, vis = bench.synth_vis(n, N, W, S, 3, dev)
+        G.copy_(torch.complex(torch.randn((N, N), dtype=torch.float64, device=dev), torch.randn((N, N), dtype=torch.float64, device=dev)))
+        out = torch.empty(n, dtype=torch.complex128, device=dev)
+        t = timed(lambda: ctx.degrid2(gcf, G, (u, v, None), wb, out))
+        report("cfg3 degrid2 (uniform)", n, t[0], {"prepass_ms": round(float(t[1]), 3), "kernel_ms": round(float(t[2]), 3)})
+        del u, v, wb, vis, out
+    del gcf, G
+if "aw" in which:
+    # config 4: aw-projection, 4096^2, 15x15, 128 planes, 512 antennas, per-antenna kernel lookup
+    N, W, Q, S, A = 4096, 128, 8, 15, 512
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4)
+    ak = torch.complex(torch.randn((A, S, S), generator=gen, device=dev, dtype=torch.float64),
+                       torch.randn((A, S, S), generator=gen, device=dev, dtype=torch.float64)) * 0.05
+    for n in (1_000_000, 10_000_000):
+        u, v, wb, vis = bench.synth_vis(n, N, W, S, 5, dev)
+        a1 = torch.randint(0, A, (n,), generator=gen, device=dev, dtype=torch.int64)
+        a2 = torch.randint(0, A, (n,), generator=gen, device=dev, dtype=torch.int64)
+        G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+        t = wall(lambda: ctx.convgrid4(gcf, ak, G, (u, v, None), (wb, a1, a2), vis), 2)
+        report(f"cfg4 aw-gridding (convgrid4), {A} antennas, no per-key kernel cache", n, t)
+        del u, v, wb, vis, a1, a2, G
