@@ -69,7 +69,8 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *   "chunk"     max visibilities per work item (0 = auto)
  *   "wgroups"   number of w-plane groups work items are split into for XCD/L2 locality (1..8; 0 = auto)
  *   "variant"   0 = LDS-tile accumulate (default), 1 = direct global-atomic scatter (baseline)
- *   "sort"      1 = order each bin by kernel slice so consecutive visibilities reuse taps (0 = off)
+ *   "sort"      order each work item's records by kernel slice in LDS so that runs of visibilities
+ *               reuse their taps from registers: 0 = auto, 1 = on (when the shape allows), 2 = off
  */
 int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value);
 int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value);

@@ -88,13 +88,26 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
         return GRIDHIP_OK;
     }
     GH_CHECK(rc);
+    // tap-reusing variant: the work item's records are sorted by slice in LDS, which bounds the chunk
+    int nkeys = 0, maxchunk = 0;
+    size_t lds_sorted = 0;
+    // sort: 0 = auto (on when a work item holds enough visibilities for slices to repeat), 1 = on, 2 = off
+    const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)g.nbins >= 256);
+    const bool sorted = want_sort && sorted_plan(ctx, g, block, &nkeys, &maxchunk, &lds_sorted);
+    // a sorted work item may span several LDS batches; keep it big enough to flush each tile once
+    if (sorted && ctx->opt.chunk == 0) g.chunk = 4 * maxchunk;
     // scratch is sized before the timed region begins
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
     mark(ctx, 0);
     GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin));
     mark(ctx, 1);
-    if (n > 0) GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, vis, grid));
+    if (n > 0) {
+        if (sorted)
+            GH_CHECK(launch_tile_grid_sorted(ctx, g, block, lds_sorted, nkeys, maxchunk, n, gcf, vis, grid));
+        else
+            GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, vis, grid));
+    }
     mark(ctx, 2);
     ctx->ev_valid = ctx->timing;
     return GRIDHIP_OK;

@@ -281,6 +281,15 @@ int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value)
 int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value)
 {
     if (!ctx || !key || !value) return GRIDHIP_EINVAL;
+    if (!strcmp(key, "errors")) {
+        // read-only: internal consistency failures counted by the last tile-kernel launch (expected 0)
+        GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+        int32_t h = 0;
+        GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_scalars + 2, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *value = h;
+        return GRIDHIP_OK;
+    }
     int64_t *s = opt_slot(ctx, key);
     if (!s) return fail(ctx, GRIDHIP_EINVAL, "unknown option '%s'", key);
     *value = *s;

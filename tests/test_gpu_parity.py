@@ -55,20 +55,36 @@ def test_convgrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
     assert ctx.last_dropped() == 0
 
 
-@pytest.mark.parametrize("tile,block,wgroups,chunk", [(8, 64, 1, 64), (16, 256, 2, 100), (32, 512, 4, 512),
-                                                      (64, 1024, 8, 4096), (64, 256, 1, 0), (32, 1024, 8, 64)])
-def test_tuning_knobs_do_not_change_results(ctx, oracle, tile, block, wgroups, chunk):
+@pytest.mark.parametrize("tile,block,wgroups,chunk,sort", [(8, 64, 1, 64, 0), (16, 256, 2, 100, 0), (32, 512, 4, 512, 0),
+                                                           (64, 1024, 8, 4096, 2), (64, 256, 1, 0, 2), (32, 1024, 8, 64, 0),
+                                                           (64, 1024, 8, 0, 1), (64, 1024, 1, 0, 1), (32, 512, 4, 700, 1),
+                                                           (64, 256, 2, 0, 1), (16, 128, 8, 0, 1)])
+def test_tuning_knobs_do_not_change_results(ctx, oracle, tile, block, wgroups, chunk, sort):
     N, W, Q, S, n = 200, 8, 4, 15, 30000
     gcf, u, v, wb, vis = case(99, N, N, W, Q, S, S, n)
     ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis)
     try:
-        for k, val in (("tile", tile), ("block", block), ("wgroups", wgroups), ("chunk", chunk)):
+        for k, val in (("tile", tile), ("block", block), ("wgroups", wgroups), ("chunk", chunk), ("sort", sort)):
             ctx.set_option(k, val)
         got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
     finally:
-        for k in ("tile", "block", "wgroups", "chunk"):
+        for k in ("tile", "block", "wgroups", "chunk", "sort"):
             ctx.set_option(k, 0)
     assert rel(got, ref) < TOL
+
+
+@pytest.mark.parametrize("dist", ["uniform", "core"])
+def test_sorted_variant_matches_oracle(ctx, oracle, dist):
+    """The tap-reusing kernel (records sorted by kernel slice in LDS, runs share registers)."""
+    for (N, W, Q, S, n) in [(512, 32, 8, 15, 150000), (300, 16, 4, 7, 80000)]:
+        gcf, u, v, wb, vis = case(7 + N, N, N, W, Q, S, S, n, dist=dist)
+        ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+        ctx.set_option("sort", 1)
+        try:
+            got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+        finally:
+            ctx.set_option("sort", 0)
+        assert rel(got, ref) < TOL
 
 
 def test_direct_variant_matches_oracle(ctx, oracle):
