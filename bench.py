@@ -221,7 +221,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "tile_grid_kernel",
+                "kernel": "tile_grid_sorted_kernel<15> (tile_grid_kernel when sort is off)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
