@@ -104,7 +104,7 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
     mark(ctx, 1);
     if (n > 0) {
         if (sorted)
-            GH_CHECK(launch_tile_grid_sorted(ctx, g, block, lds_sorted, nkeys, maxchunk, n, gcf, vis, grid));
+            GH_CHECK(launch_tile_grid_sorted(ctx, g, block, lds_sorted, nkeys, maxchunk, n, gcf, vis, grid, false));
         else
             GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, vis, grid));
     }
@@ -133,6 +133,11 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     int block;
     size_t lds;
     GH_CHECK(make_geom(ctx, H, Wd, W, Q, gh, gw, n, &g, &block, &lds));
+    int nkeys = 0, batch = 0;
+    size_t lds_sorted = 0;
+    const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)g.nbins >= 256);
+    const bool sorted = want_sort && sorted_plan(ctx, g, block, &nkeys, &batch, &lds_sorted);
+    if (sorted && ctx->opt.chunk == 0) g.chunk = 4 * batch;
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
     mark(ctx, 0);
@@ -140,7 +145,13 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     if (n > 0) GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)n * 16, ctx->stream));
     GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin));
     mark(ctx, 1);
-    if (n > 0) GH_CHECK(launch_tile_degrid(ctx, g, block, lds, n, gcf, grid, vis_out));
+    if (n > 0) {
+        if (sorted)  // the sorted kernel's degrid mode reads `grid` and writes the vis array
+            GH_CHECK(launch_tile_grid_sorted(ctx, g, block, lds_sorted, nkeys, batch, n, gcf, vis_out,
+                                             const_cast<double *>(grid), true));
+        else
+            GH_CHECK(launch_tile_degrid(ctx, g, block, lds, n, gcf, grid, vis_out));
+    }
     mark(ctx, 2);
     ctx->ev_valid = ctx->timing;
     return GRIDHIP_OK;

@@ -136,7 +136,7 @@ int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_byte
                      const double *gcf, const double *vis, double *grid);
 bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, int *maxchunk, size_t *lds_bytes);
 int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int nkeys, int maxchunk,
-                            int64_t n, const double *gcf, const double *vis, double *grid);
+                            int64_t n, const double *gcf, const double *vis, double *grid, bool degrid);
 int launch_tile_degrid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int64_t n,
                        const double *gcf, const double *grid, double *vis_out);
 int launch_direct_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,

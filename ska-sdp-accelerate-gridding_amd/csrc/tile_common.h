@@ -49,6 +49,29 @@ __device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int 
     return r;
 }
 
+// Sum of x over the 64 lanes, valid in lane 63.  Data-parallel-primitive moves only (no LDS
+// traffic, unlike __shfl which goes through ds_bpermute): an inclusive scan inside each row of 16
+// lanes (row_shr 1,2,4,8; lanes without a source add 0), then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return x + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_sum_lane63(double x)
+{
+    x = dpp_add_step<0x111, 0xf>(x);  // row_shr:1
+    x = dpp_add_step<0x112, 0xf>(x);  // row_shr:2
+    x = dpp_add_step<0x114, 0xf>(x);  // row_shr:4
+    x = dpp_add_step<0x118, 0xf>(x);  // row_shr:8
+    x = dpp_add_step<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3
+    x = dpp_add_step<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // upper bound on the number of work items (grid size of the tile kernels)
 static inline int work_blocks(const Geom &g, int64_t n)
 {

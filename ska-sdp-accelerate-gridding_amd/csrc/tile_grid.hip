@@ -224,12 +224,9 @@ __global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec 
                 ++i;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            sr += __shfl_xor(sr, off, 64);
-            si += __shfl_xor(si, off, 64);
-        }
-        if (lane == 0) vis_out[r.orig] = make_double2(sr, si);
+        sr = wave_sum_lane63(sr);
+        si = wave_sum_lane63(si);
+        if (lane == 63) vis_out[r.orig] = make_double2(sr, si);
     }
 }
 

@@ -16,12 +16,15 @@
 
 namespace gridhip {
 
-template <int S>
+// DEGRID = false: accumulate vis * taps into the tile and flush it onto `grid` (convgrid2).
+// DEGRID = true : the tile is loaded from `grid` once and each visibility's sum over taps of
+//                 taps * tile is written to vis_out[orig] (degrid2); `vis` is then the output.
+template <int S, bool DEGRID>
 __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
                                                                 const int32_t *__restrict__ work_start,
                                                                 const double2 *__restrict__ gcf,
-                                                                const double2 *__restrict__ vis,
+                                                                double2 *__restrict__ vis,
                                                                 double *__restrict__ grid, int nkeys, int batch,
                                                                 int32_t *__restrict__ scalars)
 {
@@ -47,9 +50,22 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
     const int first_plane = (grp * g.W + g.ngroups - 1) / g.ngroups;  // smallest wb with wb*ng/W == grp
     const int first_slice = first_plane * g.Q * g.Q;
 
-    {
+    const int tx = w.tile % g.ntx, ty = w.tile / g.ntx;
+    const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
+    const int ncell = g.lrows * g.lcols;
+    if (!DEGRID) {
         double2 *z = reinterpret_cast<double2 *>(lds);
         for (int i = tid; i < plane; i += nthr) z[i] = make_double2(0.0, 0.0);
+    } else {
+        const double2 *gsrc = reinterpret_cast<const double2 *>(grid);
+        for (int c = tid; c < ncell; c += nthr) {
+            const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
+            const int64_t gx = ox + c_, gy = oy + r_;
+            double2 v = make_double2(0.0, 0.0);
+            if (gx >= 0 && gy >= 0 && gx < g.Wd && gy < g.H) v = gsrc[gy * g.Wd + gx];
+            lre[r_ * g.ldw + c_] = v.x;
+            lim[r_ * g.ldw + c_] = v.y;
+        }
     }
 
     int loff[NSTEP];
@@ -111,7 +127,10 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             const int pos = atomicAdd(&hist[key], 1);
             if ((unsigned)pos < (unsigned)batch) {
                 meta[pos] = ((uint32_t)key << 16) | (uint32_t)((rec.lxy >> 16) << 8) | (uint32_t)(rec.lxy & 0xff);
-                vals[pos] = vis[rec.orig];
+                if (DEGRID)
+                    reinterpret_cast<int32_t *>(vals)[pos] = rec.orig;
+                else
+                    vals[pos] = vis[rec.orig];
             } else
                 ++bad;
         }
@@ -146,26 +165,56 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             };
             auto process = [&](const double2(&k)[NSTEP], int q0, int len) {
                 uint32_t m = meta[min(q0, seg_hi - 1)];
-                double2 v = vals[min(q0, seg_hi - 1)];
-                for (int i = 0; i < len; ++i) {
-                    const int qn = min(q0 + i + 1, seg_hi - 1);
-                    const uint32_t mn = meta[qn];  // next record's LDS reads go out before this one's atomics
-                    const double2 vn = vals[qn];
-                    const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+                if (!DEGRID) {
+                    double2 v = vals[min(q0, seg_hi - 1)];
+                    for (int i = 0; i < len; ++i) {
+                        const int qn = min(q0 + i + 1, seg_hi - 1);
+                        const uint32_t mn = meta[qn];  // next record's LDS reads go out before this one's atomics
+                        const double2 vn = vals[qn];
+                        const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
 #pragma unroll
-                    for (int s = 0; s < NSTEP; ++s) {
-                        double re = v.x * k[s].x - v.y * k[s].y;
-                        double im = v.x * k[s].y + v.y * k[s].x;
-                        if (s == NSTEP - 1 && TAIL != 64) {
-                            re = tail_ok ? re : 0.0;
-                            im = tail_ok ? im : 0.0;
+                        for (int s = 0; s < NSTEP; ++s) {
+                            double re = v.x * k[s].x - v.y * k[s].y;
+                            double im = v.x * k[s].y + v.y * k[s].x;
+                            if (s == NSTEP - 1 && TAIL != 64) {
+                                re = tail_ok ? re : 0.0;
+                                im = tail_ok ? im : 0.0;
+                            }
+                            const int a = lbase + loff[s];
+                            __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        const int a = lbase + loff[s];
-                        __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        m = mn;
+                        v = vn;
                     }
-                    m = mn;
-                    v = vn;
+                } else {
+                    const int32_t *origs = reinterpret_cast<const int32_t *>(vals);
+                    int32_t o = origs[min(q0, seg_hi - 1)];
+                    for (int i = 0; i < len; ++i) {
+                        const int qn = min(q0 + i + 1, seg_hi - 1);
+                        const uint32_t mn = meta[qn];
+                        const int32_t on = origs[qn];
+                        const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+                        double sr = 0.0, si = 0.0;
+#pragma unroll
+                        for (int s = 0; s < NSTEP; ++s) {
+                            const int a = lbase + loff[s];
+                            const double gr = lre[a], gi = lim[a];
+                            double pr = k[s].x * gr - k[s].y * gi;
+                            double pi = k[s].x * gi + k[s].y * gr;
+                            if (s == NSTEP - 1 && TAIL != 64) {
+                                pr = tail_ok ? pr : 0.0;
+                                pi = tail_ok ? pi : 0.0;
+                            }
+                            sr += pr;
+                            si += pi;
+                        }
+                        sr = wave_sum_lane63(sr);
+                        si = wave_sum_lane63(si);
+                        if (lane == 63) vis[o] = make_double2(sr, si);
+                        m = mn;
+                        o = on;
+                    }
                 }
             };
 
@@ -210,12 +259,10 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             process(kB, q, 0);
         }
     }
+    if (DEGRID) return;
     __syncthreads();
 
     // ---- flush the cells that exist in the grid
-    const int tx = w.tile % g.ntx, ty = w.tile / g.ntx;
-    const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
-    const int ncell = g.lrows * g.lcols;
     for (int c = tid; c < ncell; c += nthr) {
         const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
         const int64_t gx = ox + c_, gy = oy + r_;
@@ -253,20 +300,30 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
 }
 
 int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int nkeys, int batch,
-                            int64_t n, const double *gcf, const double *vis, double *grid)
+                            int64_t n, const double *gcf, const double *vis, double *grid, bool degrid)
 {
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
+#define GH_LAUNCH(S_, D_, BIT_)                                                                                  \
+    do {                                                                                                         \
+        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_>, BIT_));                                         \
+        hipLaunchKernelGGL((tile_grid_sorted_kernel<S_, D_>), gr, bl, lds_bytes, ctx->stream, g, recs,           \
+                           t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
+                           t.scalars);                                                                           \
+    } while (0)
     if (g.gh == 15) {
-        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<15>, 1u << 20));
-        hipLaunchKernelGGL((tile_grid_sorted_kernel<15>), gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start,
-                           t.work_start, (const double2 *)gcf, (const double2 *)vis, grid, nkeys, batch, t.scalars);
+        if (degrid)
+            GH_LAUNCH(15, true, 1u << 22);
+        else
+            GH_LAUNCH(15, false, 1u << 20);
     } else {
-        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<7>, 1u << 21));
-        hipLaunchKernelGGL((tile_grid_sorted_kernel<7>), gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start,
-                           t.work_start, (const double2 *)gcf, (const double2 *)vis, grid, nkeys, batch, t.scalars);
+        if (degrid)
+            GH_LAUNCH(7, true, 1u << 23);
+        else
+            GH_LAUNCH(7, false, 1u << 21);
     }
+#undef GH_LAUNCH
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }

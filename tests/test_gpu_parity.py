@@ -216,6 +216,27 @@ def test_degrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
     assert rel(got, ref) < TOL
 
 
+@pytest.mark.parametrize("N,W,Q,S,n,opts", [(512, 32, 8, 15, 150000, {}), (300, 16, 4, 7, 80000, {}),
+                                             (512, 32, 8, 15, 150000, {"tile": 64, "wgroups": 8}),
+                                             (256, 8, 4, 15, 60000, {"tile": 32, "block": 256, "wgroups": 2})])
+def test_degrid2_sorted_variant(ctx, oracle, N, W, Q, S, n, opts):
+    """degrid2 through the tap-reusing kernel (tile loaded into LDS once, runs share taps)."""
+    gcf, u, v, wb, vis = case(N + S, N, N, W, Q, S, S, n)
+    rng = np.random.default_rng(5)
+    G = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    ref = oracle.degrid2(gcf, G, u, v, wb)
+    try:
+        ctx.set_option("sort", 1)
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        got = ctx.degrid2(gcf, G, (u, v, None), wb)
+    finally:
+        for k in ("sort", "tile", "block", "wgroups"):
+            ctx.set_option(k, 0)
+    assert ctx.get_option("errors") == 0
+    assert rel(got, ref) < TOL
+
+
 def test_adjointness_on_device(ctx):
     """<g, grid(vis)> == <degrid_{conj K}(g), vis> — ties the two kernels together."""
     N, W, Q, S, n = 160, 4, 4, 9, 20000
