@@ -43,6 +43,11 @@ def _worker(rank, world, port, q):
     gridder = lambda k, a, p, wbin, vv: gridref_c.convgrid2(k, a, p[0], p[1], wbin, vv)  # reference-style (gcf a p wbin v)
     sharded_convgrid2(gridder, gcf, G, (u, v, None), wb, vis, rank, world)
     ref = gridref_c.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis)
+    # async form used by the overlapped reducer: the handle completes the same sum
+    from gridhip.distributed import allreduce_grid
+    H = np.full((4, 4), complex(rank + 1, -1.0))
+    allreduce_grid(H, async_op=True).wait()
+    assert np.allclose(H, complex(sum(range(1, world + 1)), -world))
     q.put((rank, float(np.abs(G - ref).max() / np.abs(ref).max())))
     dist.barrier()
     dist.destroy_process_group()
