@@ -58,9 +58,13 @@ int gridhip_device_count(int *count);
 int gridhip_create(int device, gridhip_ctx **ctx);
 int gridhip_destroy(gridhip_ctx *ctx);
 const char *gridhip_last_error(const gridhip_ctx *ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
- * context's own stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL means HIP's default
+ * (null) stream, NOT "no stream": device-pointer calls must be ordered with the caller's own
+ * kernels and copies, and those run on the null stream unless the caller created another.
+ * gridhip_reset_stream() goes back to the context's private non-blocking stream (which does not
+ * synchronise with the null stream: only use it when the inputs are known to be complete). */
 int gridhip_set_stream(gridhip_ctx *ctx, void *hip_stream);
+int gridhip_reset_stream(gridhip_ctx *ctx);
 void *gridhip_get_stream(gridhip_ctx *ctx);
 int gridhip_synchronize(gridhip_ctx *ctx);
 /* Tuning knobs (all have defaults chosen per shape):

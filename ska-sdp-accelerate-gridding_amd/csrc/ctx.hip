@@ -242,7 +242,16 @@ const char *gridhip_last_error(const gridhip_ctx *ctx) { return ctx ? ctx->err.c
 int gridhip_set_stream(gridhip_ctx *ctx, void *s)
 {
     if (!ctx) return GRIDHIP_EINVAL;
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    // NULL is a real stream: HIP's default ("null") stream, which is what torch.cuda.current_stream()
+    // is until the caller switches streams.  Work is enqueued exactly where the caller's own work is.
+    ctx->stream = (hipStream_t)s;
+    return GRIDHIP_OK;
+}
+
+int gridhip_reset_stream(gridhip_ctx *ctx)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    ctx->stream = ctx->own_stream;
     return GRIDHIP_OK;
 }
 

@@ -81,7 +81,11 @@ class Context:
         return v.value
 
     def set_stream(self, stream_ptr):
+        """Enqueue on this hipStream_t; 0/None is HIP's default (null) stream."""
         self._check(self._lib.gridhip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def reset_stream(self):
+        self._check(self._lib.gridhip_reset_stream(self._h))
 
     def synchronize(self):
         self._check(self._lib.gridhip_synchronize(self._h))

@@ -29,6 +29,7 @@ SIGNATURES = {
     "gridhip_destroy": (ci, [vp]),
     "gridhip_last_error": (C.c_char_p, [vp]),
     "gridhip_set_stream": (ci, [vp, vp]),
+    "gridhip_reset_stream": (ci, [vp]),
     "gridhip_get_stream": (vp, [vp]),
     "gridhip_synchronize": (ci, [vp]),
     "gridhip_set_option": (ci, [vp, C.c_char_p, i64]),

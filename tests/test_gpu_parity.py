@@ -269,6 +269,39 @@ def test_device_path_with_torch_tensors(ctx, oracle):
     assert rel(d.cpu().numpy(), oracle.degrid2(gcf, ref, u, v, wb)) < 1e-9
 
 
+def test_device_path_is_ordered_with_the_callers_stream(ctx):
+    """Regression: torch's current stream is HIP's null stream (pointer 0).  The device-pointer calls
+    must be enqueued THERE, behind the kernels that are still producing their inputs; a private
+    stream would read half-generated coordinates on the first call."""
+    import torch
+    dev = torch.device("cuda:0")
+    N, W, Q, S, n = 1024, 16, 8, 15, 20_000_000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    gcf = torch.complex(torch.randn((W, Q, Q, S, S), generator=gen, device=dev, dtype=torch.float64),
+                        torch.randn((W, Q, Q, S, S), generator=gen, device=dev, dtype=torch.float64))
+    torch.cuda.synchronize()
+    # a long chain of asynchronous producers, then the gridder immediately behind them
+    u = (torch.rand(n, generator=gen, device=dev, dtype=torch.float64) - 0.5) * 0.9
+    v = (torch.rand(n, generator=gen, device=dev, dtype=torch.float64) - 0.5) * 0.9
+    for _ in range(3):
+        u = torch.sin(u) * 1.0001
+        v = torch.sin(v) * 1.0001
+    wb = torch.randint(0, W, (n,), generator=gen, device=dev, dtype=torch.int64)
+    vis = torch.complex(torch.randn(n, generator=gen, device=dev, dtype=torch.float64),
+                        torch.randn(n, generator=gen, device=dev, dtype=torch.float64))
+    G1 = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    ctx.convgrid2(gcf, G1, (u, v, None), wb, vis)      # no synchronisation in between
+    s1 = G1.sum()                                       # consumer on torch's stream, again unsynchronised
+    torch.cuda.synchronize()
+    G2 = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    ctx.convgrid2(gcf, G2, (u, v, None), wb, vis)
+    torch.cuda.synchronize()
+    assert ctx.get_option("errors") == 0
+    assert ((G1 - G2).abs().max() / G2.abs().max()).item() < 1e-12
+    assert abs((s1 - G2.sum()).item()) / G2.abs().sum().item() < 1e-12
+
+
 def test_baseline_config2_full_size(ctx, oracle):
     """BASELINE.json configs[1]: 10^6 vis, 2048^2 grid, 7x7 support — small enough to compare outright."""
     N, W, Q, S, n = 2048, 16, 8, 7, 1_000_000
