@@ -59,7 +59,6 @@ struct gridhip_ctx {
     gridhip::Options opt;
     // device scratch, grown on demand (never inside a timed/captured region after warm-up)
     gridhip::Workspace recs;    // VisRec[n]
-    gridhip::Workspace keys;    // per-visibility sort keys / temporaries
     gridhip::Workspace tables;  // bin_count / bin_start / work_start / cursors / scalars
     gridhip::Workspace stage;   // staging for the host-pointer entry points
     int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=last call's n; 16 ints

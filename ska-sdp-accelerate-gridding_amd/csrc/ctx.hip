@@ -20,8 +20,8 @@ int fail(gridhip_ctx *ctx, int code, const char *fmt, ...)
 int ws_reserve(gridhip_ctx *ctx, Workspace &ws, size_t bytes)
 {
     if (bytes <= ws.bytes) return GRIDHIP_OK;
-    // growing scratch: the stream may still be reading the old block
-    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // growing scratch: earlier calls (possibly on another stream) may still be reading the old block
+    GH_CHECK_HIP(ctx, hipDeviceSynchronize());
     if (ws.ptr) GH_CHECK_HIP(ctx, hipFree(ws.ptr));
     ws.ptr = nullptr;
     ws.bytes = 0;
@@ -226,7 +226,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     fft_release(ctx);
-    Workspace *all[] = {&ctx->recs, &ctx->keys, &ctx->tables, &ctx->stage};
+    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
