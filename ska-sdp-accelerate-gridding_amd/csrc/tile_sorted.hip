@@ -35,7 +35,6 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
     constexpr int S2 = S * S;
     constexpr int NSTEP = (S2 + 63) / 64;
     constexpr int TAIL = S2 - (NSTEP - 1) * 64;
-    constexpr int RPT = 4;  // records per thread per batch
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const int plane = g.lrows * g.ldw;
@@ -87,19 +86,11 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
         // ---- counting sort of this batch's records by kernel slice ---------------------------
         __syncthreads();  // previous batch fully consumed (and, first time, the tile zeroed)
         for (int i = tid; i <= nkeys; i += nthr) hist[i] = 0;
-        // this thread's records of the batch stay in registers across the three sort phases
-        // (batch <= RPT * blockDim, sorted_plan); all their loads are issued before the first wait
-        VisRec rec[RPT];
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int r = tid + j * nthr;
-            rec[j] = load_rec(recs, b_lo + min(r, cnt - 1));
-        }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int key = rec[j].kslice - first_slice;
-            if (tid + j * nthr < cnt && (unsigned)key < (unsigned)nkeys) atomicAdd(&hist[key], 1);
+        for (int r = tid; r < cnt; r += nthr) {
+            const VisRec rec = load_rec(recs, b_lo + r);
+            const int key = rec.kslice - first_slice;
+            if ((unsigned)key < (unsigned)nkeys) atomicAdd(&hist[key], 1);
         }
         __syncthreads();
         {   // exclusive scan of hist[0..nkeys): each thread owns a contiguous strip
@@ -124,29 +115,22 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                 base += c;
             }
         }
-        // the value gathers (random 16-byte reads) go out together, ahead of the barrier
-        double2 val[RPT];
-        if (!DEGRID) {
-#pragma unroll
-            for (int j = 0; j < RPT; ++j) val[j] = vis[rec[j].orig];
-        }
         __syncthreads();
         int bad = 0;
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            if (tid + j * nthr >= cnt) continue;
-            const int key = rec[j].kslice - first_slice;
+        for (int r = tid; r < cnt; r += nthr) {
+            const VisRec rec = load_rec(recs, b_lo + r);
+            const int key = rec.kslice - first_slice;
             if ((unsigned)key >= (unsigned)nkeys) {  // cannot happen unless binning and kernel disagree
                 ++bad;
                 continue;
             }
             const int pos = atomicAdd(&hist[key], 1);
             if ((unsigned)pos < (unsigned)batch) {
-                meta[pos] = ((uint32_t)key << 16) | (uint32_t)((rec[j].lxy >> 16) << 8) | (uint32_t)(rec[j].lxy & 0xff);
+                meta[pos] = ((uint32_t)key << 16) | (uint32_t)((rec.lxy >> 16) << 8) | (uint32_t)(rec.lxy & 0xff);
                 if (DEGRID)
-                    reinterpret_cast<int32_t *>(vals)[pos] = rec[j].orig;
+                    reinterpret_cast<int32_t *>(vals)[pos] = rec.orig;
                 else
-                    vals[pos] = val[j];
+                    vals[pos] = vis[rec.orig];
             } else
                 ++bad;
         }
@@ -305,8 +289,9 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     const size_t hist = (size_t)((keys + 1 + 3) & ~3) * 4;
     if (tile + hist + 512 * 20 + 512 > (size_t)ctx->max_lds) return false;
     int c = (int)(((size_t)ctx->max_lds - 512 - tile - hist) / 20);
+    (void)block;
     c &= ~63;
-    if (c > 4 * block) c = 4 * block;  // the kernel keeps 4 records per thread in registers
+    if (c > 8192) c = 8192;
     if (c < 512) return false;
     *nkeys = (int)keys;
     *batch = c;
