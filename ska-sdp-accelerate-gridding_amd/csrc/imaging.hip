@@ -522,32 +522,47 @@ static int build_wkernels(gridhip_ctx *ctx, double theta, int64_t wstep, int64_t
     return GRIDHIP_OK;
 }
 
-// w_cache_imaging body on device pointers (src/Gridding.hs:399-449): u,v,w in wavelengths, grid zeroed N x N
-static int w_cache_grid_dev(gridhip_ctx *ctx, double theta, int64_t lam, int64_t wstep, int64_t Q, int64_t npixFF,
-                            int64_t S, int64_t N, int64_t n, const double *u, const double *v, const double *w,
-                            const double *vis, double *grid)
+// What w_cache_imaging (src/Gridding.hs:399-449) derives from the baselines alone: scaled u, v, the
+// w-bins and one conjugated w-kernel per plane.  do_imaging calls the imaging function twice with the
+// same baselines (image and PSF, :538,541); the reference rebuilds everything both times ("no cache
+// despite the name", :405-411) — here the second call reuses it.
+struct WCache {
+    DevBuf pu, pv, wb, table;
+    int64_t nplanes = 0;
+    bool ready = false;
+};
+
+static int w_cache_prepare(gridhip_ctx *ctx, WCache &c, double theta, int64_t lam, int64_t wstep, int64_t Q,
+                           int64_t npixFF, int64_t S, int64_t n, const double *u, const double *v, const double *w)
 {
-    DevBuf pu, pv, wb;
-    GH_CHECK(pu.alloc(ctx, n * 8));
-    GH_CHECK(pv.alloc(ctx, n * 8));
-    GH_CHECK(wb.alloc(ctx, n * 8));
+    GH_CHECK(c.pu.alloc(ctx, n * 8));
+    GH_CHECK(c.pv.alloc(ctx, n * 8));
+    GH_CHECK(c.wb.alloc(ctx, n * 8));
     if (n > 0) {
         hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, u, (int64_t)1, (double)lam,
-                           pu.as<double>());
+                           c.pu.as<double>());
         hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, v, (int64_t)1, (double)lam,
-                           pv.as<double>());
+                           c.pv.as<double>());
     }
-    int64_t wmin = 0, nplanes = 0;
-    GH_CHECK(dev_wbins(ctx, n, w, 1, wstep, wb.as<int64_t>(), &wmin, &nplanes));
-    if (n == 0 || nplanes == 0) return GRIDHIP_OK;
-    if (nplanes > 65536) return fail(ctx, GRIDHIP_EUNSUPPORTED, "%lld w-planes", (long long)nplanes);
-    DevBuf table;
-    GH_CHECK(table.alloc(ctx, (size_t)nplanes * Q * Q * S * S * 16));
-    GH_CHECK(build_wkernels(ctx, theta, wstep, wmin, nplanes, npixFF, S, Q, table.as<double2>()));
-    GH_CHECK(gridhip_convgrid2_dev(ctx, N, N, grid, n, nplanes, Q, S, S, table.as<double>(), pu.as<double>(),
-                                   pv.as<double>(), 1, wb.as<int64_t>(), vis));
-    GH_CHECK(sync(ctx));
-    return GRIDHIP_OK;
+    int64_t wmin = 0;
+    GH_CHECK(dev_wbins(ctx, n, w, 1, wstep, c.wb.as<int64_t>(), &wmin, &c.nplanes));
+    c.ready = true;
+    if (n == 0 || c.nplanes == 0) return GRIDHIP_OK;
+    if (c.nplanes > 65536) return fail(ctx, GRIDHIP_EUNSUPPORTED, "%lld w-planes", (long long)c.nplanes);
+    GH_CHECK(c.table.alloc(ctx, (size_t)c.nplanes * Q * Q * S * S * 16));
+    return build_wkernels(ctx, theta, wstep, wmin, c.nplanes, npixFF, S, Q, c.table.as<double2>());
+}
+
+// u,v,w in wavelengths, grid zeroed N x N
+static int w_cache_grid_dev(gridhip_ctx *ctx, WCache &c, double theta, int64_t lam, int64_t wstep, int64_t Q,
+                            int64_t npixFF, int64_t S, int64_t N, int64_t n, const double *u, const double *v,
+                            const double *w, const double *vis, double *grid)
+{
+    if (!c.ready) GH_CHECK(w_cache_prepare(ctx, c, theta, lam, wstep, Q, npixFF, S, n, u, v, w));
+    if (n == 0 || c.nplanes == 0) return GRIDHIP_OK;
+    GH_CHECK(gridhip_convgrid2_dev(ctx, N, N, grid, n, c.nplanes, Q, S, S, c.table.as<double>(), c.pu.as<double>(),
+                                   c.pv.as<double>(), 1, c.wb.as<int64_t>(), vis));
+    return sync(ctx);
 }
 
 }  // namespace gridhip
@@ -825,7 +840,8 @@ int gridhip_w_cache_imaging(gridhip_ctx *ctx, int64_t wstep, int64_t qpx, int64_
     GH_CHECK(stage3(ctx, n, u, v, w, uv_stride, vis, du, dv, dw, dvis));
     GH_CHECK(dg.alloc(ctx, (size_t)N * N * 16));
     GH_CHECK_HIP(ctx, hipMemsetAsync(dg.p, 0, (size_t)N * N * 16, ctx->stream));
-    GH_CHECK(w_cache_grid_dev(ctx, theta, lam, wstep, qpx, npixFF, npixKern, N, n, du.as<double>(), dv.as<double>(),
+    WCache cache;
+    GH_CHECK(w_cache_grid_dev(ctx, cache, theta, lam, wstep, qpx, npixFF, npixKern, N, n, du.as<double>(), dv.as<double>(),
                               dw.as<double>(), dvis.as<double>(), dg.as<double>()));
     GH_CHECK(d2h(ctx, grid, dg.p, (size_t)N * N * 16));
     return sync(ctx);
@@ -906,11 +922,12 @@ int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int
     } else if (kind == 2) {
         if (wstep <= 0) wstep = 2000;
         if (Q <= 0 || npixFF <= 0 || gh <= 0 || gh > npixFF) return fail(ctx, GRIDHIP_EINVAL, "bad kernel options");
+        WCache cache;  // built by the image pass, reused by the PSF pass
         return do_imaging_impl(ctx, theta, lam, n, u, v, w, uv_stride, vis, image, psf, pmax,
                                [&](int64_t N, const double *uu, const double *vv, const double *ww, const double *vs,
                                    double *g) {
-                                   return w_cache_grid_dev(ctx, theta, lam, wstep, Q, npixFF, gh, N, n, uu, vv, ww, vs,
-                                                           g);
+                                   return w_cache_grid_dev(ctx, cache, theta, lam, wstep, Q, npixFF, gh, N, n, uu, vv,
+                                                           ww, vs, g);
                                });
     }
     return fail(ctx, GRIDHIP_EINVAL, "unknown imaging function %d", kind);
