@@ -251,8 +251,16 @@ int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_byte
             GH_LAUNCH(15, 3, 1u << 18);
         else
             GH_LAUNCH(15, 0, 1u << 2);
-    } else if (g.gh == 7 && g.gw == 7)
+    } else if (g.gh == g.gw && g.gh == 5)
+        GH_LAUNCH(5, 0, 1u << 5);
+    else if (g.gh == g.gw && g.gh == 7)
         GH_LAUNCH(7, 0, 1u << 3);
+    else if (g.gh == g.gw && g.gh == 9)
+        GH_LAUNCH(9, 0, 1u << 6);
+    else if (g.gh == g.gw && g.gh == 11)
+        GH_LAUNCH(11, 0, 1u << 7);
+    else if (g.gh == g.gw && g.gh == 13)
+        GH_LAUNCH(13, 0, 1u << 8);
     else
         GH_LAUNCH(0, 0, 1u << 4);
 #undef GH_LAUNCH

@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
 // staged records.  On success returns the LDS bytes and the batch size.
 bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, int *batch, size_t *lds_bytes)
 {
-    if (!((g.gh == 15 && g.gw == 15) || (g.gh == 7 && g.gw == 7))) return false;
+    // square odd supports with a compile-time instantiation below
+    if (g.gh != g.gw || g.gh < 5 || g.gh > 15 || !(g.gh & 1)) return false;
     if (g.per_vis || g.T > 128) return false;
     const int planes = (g.W + g.ngroups - 1) / g.ngroups + 1;  // groups differ by at most one plane
     const int64_t keys = (int64_t)planes * g.Q * g.Q;
@@ -312,16 +313,21 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
                            t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
                            t.scalars);                                                                           \
     } while (0)
-    if (g.gh == 15) {
-        if (degrid)
-            GH_LAUNCH(15, true, 1u << 22);
-        else
-            GH_LAUNCH(15, false, 1u << 20);
-    } else {
-        if (degrid)
-            GH_LAUNCH(7, true, 1u << 23);
-        else
-            GH_LAUNCH(7, false, 1u << 21);
+    // attr_mask bits 20..31: one per instantiation
+    switch (g.gh * 2 + (degrid ? 1 : 0)) {
+        case 5 * 2: GH_LAUNCH(5, false, 1u << 20); break;
+        case 5 * 2 + 1: GH_LAUNCH(5, true, 1u << 21); break;
+        case 7 * 2: GH_LAUNCH(7, false, 1u << 22); break;
+        case 7 * 2 + 1: GH_LAUNCH(7, true, 1u << 23); break;
+        case 9 * 2: GH_LAUNCH(9, false, 1u << 24); break;
+        case 9 * 2 + 1: GH_LAUNCH(9, true, 1u << 25); break;
+        case 11 * 2: GH_LAUNCH(11, false, 1u << 26); break;
+        case 11 * 2 + 1: GH_LAUNCH(11, true, 1u << 27); break;
+        case 13 * 2: GH_LAUNCH(13, false, 1u << 28); break;
+        case 13 * 2 + 1: GH_LAUNCH(13, true, 1u << 29); break;
+        case 15 * 2: GH_LAUNCH(15, false, 1u << 30); break;
+        case 15 * 2 + 1: GH_LAUNCH(15, true, 1u << 31); break;
+        default: return fail(ctx, GRIDHIP_EUNSUPPORTED, "no sorted instantiation for support %d", g.gh);
     }
 #undef GH_LAUNCH
     GH_CHECK_HIP(ctx, hipGetLastError());

@@ -43,6 +43,10 @@ SHAPES = [
     (50, 50, 5, 2, 3, 3, 4000),
     (33, 47, 2, 4, 2, 4, 2000),         # even supports, odd grid sizes
     (300, 300, 16, 8, 15, 15, 50000),
+    (160, 160, 4, 4, 9, 9, 20000),      # the other compile-time supports of the pipelined kernel
+    (160, 160, 4, 4, 11, 11, 20000),
+    (160, 160, 4, 2, 13, 13, 20000),
+    (160, 160, 4, 4, 5, 5, 20000),
 ]
 
 
@@ -76,7 +80,8 @@ def test_tuning_knobs_do_not_change_results(ctx, oracle, tile, block, wgroups, c
 @pytest.mark.parametrize("dist", ["uniform", "core"])
 def test_sorted_variant_matches_oracle(ctx, oracle, dist):
     """The tap-reusing kernel (records sorted by kernel slice in LDS, runs share registers)."""
-    for (N, W, Q, S, n) in [(512, 32, 8, 15, 150000), (300, 16, 4, 7, 80000)]:
+    for (N, W, Q, S, n) in [(512, 32, 8, 15, 150000), (300, 16, 4, 7, 80000), (256, 8, 4, 9, 60000),
+                            (256, 8, 4, 11, 60000), (256, 8, 2, 13, 60000), (200, 4, 4, 5, 50000)]:
         gcf, u, v, wb, vis = case(7 + N, N, N, W, Q, S, S, n, dist=dist)
         ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
         ctx.set_option("sort", 1)
@@ -217,6 +222,7 @@ def test_degrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
 
 
 @pytest.mark.parametrize("N,W,Q,S,n,opts", [(512, 32, 8, 15, 150000, {}), (300, 16, 4, 7, 80000, {}),
+                                             (256, 8, 4, 9, 60000, {}), (256, 8, 2, 13, 60000, {}),
                                              (512, 32, 8, 15, 150000, {"tile": 64, "wgroups": 8}),
                                              (256, 8, 4, 15, 60000, {"tile": 32, "block": 256, "wgroups": 2})])
 def test_degrid2_sorted_variant(ctx, oracle, N, W, Q, S, n, opts):
