@@ -1,9 +1,11 @@
 // Binning pre-pass: turn the caller's (u, v, wbin, vis) stream into tile-ordered VisRec
 // records so that the tile kernels can accumulate a whole grid tile in LDS.
 //
-//   bin_count   : histogram of visibilities per bin (bin = w-group x grid tile), LDS-privatised
+//   bin_count   : histogram of visibilities per bin (bin = w-group x grid tile), LDS-privatised; each
+//                 work-group also keeps its own histogram
 //   bin_scan    : exclusive scans -> bin_start[], per-group work_start[] (chunks of <=chunk vis)
-//   bin_scatter : second sweep writes each visibility's VisRec into its bin's slot range
+//   bin_offsets : per-work-group histograms -> each work-group's first slot in every bin
+//   bin_scatter : second sweep writes each visibility's VisRec into its work-group's slot range
 //
 // Coordinates follow frac_coords / convgrid2 of src/Gridding.hs:126-151,212-218: the footprint
 // origin is (x - gw/2, y - gh/2); a visibility none of whose taps can land inside the grid is
@@ -64,6 +66,7 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
                                                          const double *__restrict__ v, int64_t stride,
                                                          const int64_t *__restrict__ wbin,
                                                          int32_t *__restrict__ bin_count,
+                                                         int32_t *__restrict__ block_hist,
                                                          int32_t *__restrict__ scalars)
 {
     extern __shared__ int32_t hist[];
@@ -87,10 +90,30 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
     if (dropped) atomicAdd(&scalars[0], dropped);
     if (LDS_HIST) {
         __syncthreads();
+        // keep this block's histogram: bin_offsets_kernel turns it into the block's first slot per
+        // bin, so the scatter pass needs neither a recount nor slot-reservation atomics
+        int32_t *mine = block_hist + (size_t)blockIdx.x * g.nbins;
         for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) {
             int c = hist[i];
+            mine[i] = c;
             if (c) atomicAdd(&bin_count[i], c);
         }
+    }
+}
+
+// block_hist[b][bin] (count) -> first slot of block b inside bin: bin_start[bin] + counts of the
+// blocks before it.  One thread per bin, coalesced across bins.
+__global__ void __launch_bounds__(256) bin_offsets_kernel(int nbins, int nblocks, const int32_t *__restrict__ bin_start,
+                                                          int32_t *__restrict__ block_hist)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= nbins) return;
+    int run = bin_start[bin];
+    for (int b = 0; b < nblocks; ++b) {
+        int32_t *p = block_hist + (size_t)b * nbins + bin;
+        const int c = *p;
+        *p = run;
+        run += c;
     }
 }
 
@@ -168,28 +191,19 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
                                                            const int64_t *__restrict__ wbin,
                                                            const int32_t *__restrict__ bin_start,
                                                            int32_t *__restrict__ cursor,
+                                                           const int32_t *__restrict__ block_hist,
                                                            VisRec *__restrict__ recs)
 {
     extern __shared__ int32_t hist[];
     int64_t lo, hi;
     block_range(n, &lo, &hi);
     if (LDS_HIST) {
-        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        // sweep 1: how many of this block's visibilities go to each bin
-        for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-            BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
-            if (b.bin >= 0) atomicAdd(&hist[b.bin], 1);
-        }
-        __syncthreads();
-        // reserve one contiguous slot range per (block, bin); hist[] becomes the next free slot
-        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) {
-            int c = hist[i];
-            if (c) hist[i] = bin_start[i] + atomicAdd(&cursor[i], c);
-        }
+        // hist[bin] = this block's next free slot in the bin (its range was fixed by bin_offsets_kernel)
+        const int32_t *mine = block_hist + (size_t)blockIdx.x * g.nbins;
+        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) hist[i] = mine[i];
         __syncthreads();
     }
-    // sweep 2: write the records
+    // write the records
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
         if (b.bin < 0) continue;
@@ -213,6 +227,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
     Tables t = tables_of(ctx, g);
+    int32_t *block_hist = nullptr;
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.bin_count, 0, (size_t)g.nbins * sizeof(int32_t), ctx->stream));
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars, 0, 16 * sizeof(int32_t), ctx->stream));
 
@@ -221,11 +236,15 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     const int threads = 1024;
     // one block per CU with an LDS histogram; more, smaller slices when counting in global memory
     int blocks = lds_hist ? ctx->num_cu * (hist_bytes <= 64 * 1024 ? 2 : 1) : ctx->num_cu * 8;
-    int64_t need = (n + threads - 1) / threads;
+    // at least 16 K visibilities per work-group: below that the per-work-group histogram traffic
+    // (and the serial walk over work-groups in bin_offsets_kernel) outweighs the parallelism
+    int64_t need = (n + 16383) / 16384;
     if (need < 1) need = 1;
     if (blocks > need) blocks = (int)need;
 
     if (lds_hist) {
+        GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)blocks * g.nbins * sizeof(int32_t)));
+        block_hist = (int32_t *)ctx->blockhist.ptr;
         if (!(ctx->attr_mask & 1u)) {
             GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
@@ -234,19 +253,21 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             ctx->attr_mask |= 1u;
         }
         hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
-                           v, uv_stride, wbin, t.bin_count, t.scalars);
+                           v, uv_stride, wbin, t.bin_count, block_hist, t.scalars);
     } else {
         hipLaunchKernelGGL(bin_count_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_count, t.scalars);
+                           uv_stride, wbin, t.bin_count, block_hist, t.scalars);
     }
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                        t.work_start, t.cursor);
-    if (lds_hist)
+    if (lds_hist) {
+        hipLaunchKernelGGL(bin_offsets_kernel, dim3((g.nbins + 255) / 256), dim3(256), 0, ctx->stream, g.nbins, blocks,
+                           t.bin_start, block_hist);
         hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n,
-                           u, v, uv_stride, wbin, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
-    else
+                           u, v, uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr);
+    } else
         hipLaunchKernelGGL(bin_scatter_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_start, t.cursor, (VisRec *)ctx->recs.ptr);
+                           uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr);
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }

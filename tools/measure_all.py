@@ -48,6 +48,18 @@ def report(name, n, t_ms, extra=None):
 
 
 which = sys.argv[1:] or ["cfg2", "core", "degrid", "aw"]
+if "host" in which:
+    # PCIe-inclusive rate of the drop-in host-pointer ABI (pageable numpy arrays in, grid out)
+    n, N, W, Q, S = 20_000_000, 4096, 128, 8, 15
+    gcf = bench.synth_kernels(W, Q, S, dev).cpu().numpy()
+    u, v, wb, vis = (t.cpu().numpy() for t in bench.synth_vis(n, N, W, S, 9, dev))
+    G = np.zeros((N, N), dtype=np.complex128)
+    ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+    t0 = time.perf_counter()
+    ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+    dt = (time.perf_counter() - t0) * 1e3
+    report("cfg3 shape through the HOST-pointer ABI (H2D of 48 B/vis + 29.5 MB kernels + 256 MiB grid both ways)", n, dt)
+    del gcf, u, v, wb, vis, G
 if "cfg2" in which:
     n, N, W, Q, S = bench.WORKLOADS["cfg2"]
     gcf = bench.synth_kernels(W, Q, S, dev)
