@@ -123,6 +123,22 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
                         const double *gcf, const double *u, const double *v,
                         int64_t uv_stride, const int64_t *wbin, double *vis_out);
 
+/* ---- plans: bin the baselines once, grid / degrid many times (device pointers) ----------------
+ * The binning pre-pass depends on (u, v, wbin) and the kernel-table SHAPE only.  do_imaging grids
+ * the same baselines twice (image and PSF, src/Gridding.hs:538,541) and major cycles alternate
+ * degrid / grid over them; a plan keeps the tile-ordered records resident so each further pass is
+ * the tile kernel alone.  The coordinate arrays may be released after gridhip_plan_create_dev
+ * returns and the stream has run; vis / grid / gcf are per call.  A plan belongs to its context
+ * (same device, same stream, not thread-safe) and must be destroyed before it. */
+typedef struct gridhip_plan gridhip_plan;
+int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, int64_t W, int64_t Q,
+                            int64_t gh, int64_t gw, const double *u, const double *v,
+                            int64_t uv_stride, const int64_t *wbin, gridhip_plan **plan);
+int gridhip_plan_grid_dev(gridhip_plan *plan, const double *gcf, const double *vis, double *grid);
+int gridhip_plan_degrid_dev(gridhip_plan *plan, const double *gcf, const double *grid,
+                            double *vis_out);
+int gridhip_plan_destroy(gridhip_plan *plan);
+
 /* ---- callers either side of the gridder (host pointers) -------------------------
  * All follow src/Gridding.hs; uvw are in wavelengths where the reference takes them so. */
 

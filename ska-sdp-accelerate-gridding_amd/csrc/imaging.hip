@@ -530,6 +530,8 @@ struct WCache {
     DevBuf pu, pv, wb, table;
     int64_t nplanes = 0;
     bool ready = false;
+    gridhip_plan *plan = nullptr;  // the baselines binned once for both passes
+    ~WCache() { gridhip_plan_destroy(plan); }
 };
 
 static int w_cache_prepare(gridhip_ctx *ctx, WCache &c, double theta, int64_t lam, int64_t wstep, int64_t Q,
@@ -560,8 +562,10 @@ static int w_cache_grid_dev(gridhip_ctx *ctx, WCache &c, double theta, int64_t l
 {
     if (!c.ready) GH_CHECK(w_cache_prepare(ctx, c, theta, lam, wstep, Q, npixFF, S, n, u, v, w));
     if (n == 0 || c.nplanes == 0) return GRIDHIP_OK;
-    GH_CHECK(gridhip_convgrid2_dev(ctx, N, N, grid, n, c.nplanes, Q, S, S, c.table.as<double>(), c.pu.as<double>(),
-                                   c.pv.as<double>(), 1, c.wb.as<int64_t>(), vis));
+    if (!c.plan)
+        GH_CHECK(gridhip_plan_create_dev(ctx, N, N, n, c.nplanes, Q, S, S, c.pu.as<double>(), c.pv.as<double>(), 1,
+                                         c.wb.as<int64_t>(), &c.plan));
+    GH_CHECK(gridhip_plan_grid_dev(c.plan, c.table.as<double>(), vis, grid));
     return sync(ctx);
 }
 

@@ -195,6 +195,22 @@ class Context:
         return out
 
 
+    def plan(self, grid_shape, gcf_shape, p, wbin):
+        """Bin the baselines `p` (torch cuda tensors) once for an [H, W] grid and a [W,Q,Q,gh,gw] kernel
+        table; returns a Plan whose grid()/degrid() skip the pre-pass."""
+        import torch
+        u, v, stride = _split_p(p)
+        if stride == 1:
+            u, v = u.to(torch.float64).contiguous(), v.to(torch.float64).contiguous()
+        wbin = None if wbin is None else wbin.to(torch.int64).contiguous()
+        self._use_torch_stream()
+        W, Q, _, gh, gw = gcf_shape
+        h = C.c_void_p()
+        self._check(self._lib.gridhip_plan_create_dev(self._h, grid_shape[0], grid_shape[1], int(u.shape[0]), W, Q, gh,
+                                                      gw, self._ptr(u), self._ptr(v), stride, self._ptr(wbin),
+                                                      C.byref(h)))
+        return Plan(self, h, int(u.shape[0]), tuple(grid_shape), tuple(gcf_shape))
+
     def convgrid4(self, wkerns, akerns, a, p, index, v):
         """src/Gridding.hs:318-396 ; index = (wbin, a1, a2) arrays.  convgrid3 (:246-317) gives the same grid."""
         wbin, a1, a2 = index
@@ -361,6 +377,46 @@ class Context:
                                                  int(lam), len(vis), self._ptr(u), self._ptr(v), self._ptr(w), st,
                                                  self._ptr(vis), self._ptr(img), self._ptr(psf), C.byref(pmax)))
         return img, psf, pmax.value
+
+
+class Plan:
+    """Baselines binned once (gridhip_plan); grid()/degrid() run the tile kernel only."""
+
+    def __init__(self, ctx, handle, n, grid_shape, gcf_shape):
+        self.ctx, self._h, self.n, self.grid_shape, self.gcf_shape = ctx, handle, n, grid_shape, gcf_shape
+
+    def _chk(self, gcf, a):
+        assert tuple(gcf.shape) == self.gcf_shape and tuple(a.shape) == self.grid_shape
+        assert gcf.is_cuda and a.is_cuda and gcf.is_contiguous() and a.is_contiguous()
+        self.ctx._use_torch_stream()
+
+    def grid(self, gcf, a, v):
+        """a += convgrid2 contributions of visibilities v (cuda complex128, length n)"""
+        self._chk(gcf, a)
+        assert v.shape[0] == self.n and v.is_contiguous()
+        self.ctx._check(self.ctx._lib.gridhip_plan_grid_dev(self._h, Context._ptr(gcf), Context._ptr(v),
+                                                            Context._ptr(a)))
+        return a
+
+    def degrid(self, gcf, a, out=None):
+        import torch
+        self._chk(gcf, a)
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.complex128, device=a.device)
+        self.ctx._check(self.ctx._lib.gridhip_plan_degrid_dev(self._h, Context._ptr(gcf), Context._ptr(a),
+                                                              Context._ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            self.ctx._lib.gridhip_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default = {}

@@ -43,6 +43,10 @@ SIGNATURES = {
     "gridhip_convgrid_dev": (ci, _CONV_DEV),
     "gridhip_convgrid2_dev": (ci, _CONV2_DEV),
     "gridhip_degrid2_dev": (ci, _CONV2_DEV),
+    "gridhip_plan_create_dev": (ci, [vp, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, C.POINTER(vp)]),
+    "gridhip_plan_grid_dev": (ci, [vp, vp, vp, vp]),
+    "gridhip_plan_degrid_dev": (ci, [vp, vp, vp, vp]),
+    "gridhip_plan_destroy": (ci, [vp]),
     "gridhip_image_size": (i64, [C.c_double, i64]),
     "gridhip_wbins": (ci, [vp, i64, vp, i64, vp, C.POINTER(i64), C.POINTER(i64)]),
     "gridhip_find_closest": (ci, [vp, i64, vp, i64, vp, vp]),

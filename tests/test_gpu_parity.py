@@ -308,6 +308,32 @@ def test_device_path_is_ordered_with_the_callers_stream(ctx):
     assert abs((s1 - G2.sum()).item()) / G2.abs().sum().item() < 1e-12
 
 
+@pytest.mark.parametrize("N,W,Q,S,n", [(512, 32, 8, 15, 200000), (200, 4, 2, 9, 3000), (128, 2, 2, 6, 4000)])
+def test_plan_bins_once_grids_and_degrids_many_times(ctx, oracle, N, W, Q, S, n):
+    """gridhip_plan_*: the records are independent of the visibility and kernel values."""
+    import torch
+    dev = torch.device("cuda:0")
+    gcf, u, v, wb, vis = case(N + n, N, N, W, Q, S, S, n)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tg, tu, tv, twb = t(gcf), t(u), t(v), t(wb)
+    plan = ctx.plan((N, N), gcf.shape, (tu, tv, None), twb)
+    del tu, tv, twb  # the coordinates are no longer needed
+    vis2 = vis[::-1].copy() * (0.5 - 2j)
+    gcf2 = np.conj(gcf) * 1.5
+    for k, (kk, vv) in enumerate([(gcf, vis), (gcf, vis2), (gcf2, vis)]):
+        G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+        plan.grid(t(kk), G, t(vv))
+        torch.cuda.synchronize()
+        ref = oracle.convgrid2(kk, np.zeros((N, N), dtype=np.complex128), u, v, wb, vv)
+        assert rel(G.cpu().numpy(), ref) < TOL, k
+    rng = np.random.default_rng(3)
+    Gd = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    d = plan.degrid(tg, t(Gd))
+    torch.cuda.synchronize()
+    assert rel(d.cpu().numpy(), oracle.degrid2(gcf, Gd, u, v, wb)) < TOL
+    plan.close()
+
+
 def test_baseline_config2_full_size(ctx, oracle):
     """BASELINE.json configs[1]: 10^6 vis, 2048^2 grid, 7x7 support — small enough to compare outright."""
     N, W, Q, S, n = 2048, 16, 8, 7, 1_000_000

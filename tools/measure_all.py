@@ -60,6 +60,19 @@ if "host" in which:
     dt = (time.perf_counter() - t0) * 1e3
     report("cfg3 shape through the HOST-pointer ABI (H2D of 48 B/vis + 29.5 MB kernels + 256 MiB grid both ways)", n, dt)
     del gcf, u, v, wb, vis, G
+if "plan" in which:
+    n, N, W, Q, S = bench.WORKLOADS["cfg3"]
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    u, v, wb, vis = bench.synth_vis(n, N, W, S, 6, dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    out = torch.empty(n, dtype=torch.complex128, device=dev)
+    t = wall(lambda: ctx.plan((N, N), tuple(gcf.shape), (u, v, None), wb).close())
+    report("cfg3 plan creation (binning only)", n, t)
+    plan = ctx.plan((N, N), tuple(gcf.shape), (u, v, None), wb)
+    report("cfg3 grid through a plan (no pre-pass)", n, wall(lambda: plan.grid(gcf, G, vis), 5))
+    report("cfg3 degrid through a plan (no pre-pass)", n, wall(lambda: plan.degrid(gcf, G, out), 5))
+    plan.close()
+    del gcf, u, v, wb, vis, G, out
 if "cfg2" in which:
     n, N, W, Q, S = bench.WORKLOADS["cfg2"]
     gcf = bench.synth_kernels(W, Q, S, dev)
