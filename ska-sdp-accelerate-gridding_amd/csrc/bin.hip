@@ -67,11 +67,14 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
                                                          const int64_t *__restrict__ wbin,
                                                          int32_t *__restrict__ bin_count,
                                                          int32_t *__restrict__ block_hist,
-                                                         int32_t *__restrict__ scalars)
+                                                         int32_t *__restrict__ scalars, int bin_lo, int bin_hi)
 {
+    // LDS_HIST: this launch handles the bins [bin_lo, bin_hi) only (a window that fits in LDS); grids
+    // with more bins than that are covered by several launches, each a full sweep of the stream.
     extern __shared__ int32_t hist[];
+    const int nwin = bin_hi - bin_lo;
     if (LDS_HIST) {
-        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) hist[i] = 0;
+        for (int i = threadIdx.x; i < nwin; i += blockDim.x) hist[i] = 0;
         __syncthreads();
     }
     int64_t lo, hi;
@@ -80,23 +83,23 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
         if (b.bin >= 0) {
-            if (LDS_HIST)
-                atomicAdd(&hist[b.bin], 1);
-            else
+            if (LDS_HIST) {
+                if (b.bin >= bin_lo && b.bin < bin_hi) atomicAdd(&hist[b.bin - bin_lo], 1);
+            } else
                 atomicAdd(&bin_count[b.bin], 1);
         } else if (b.bin == -2)
             ++dropped;
     }
-    if (dropped) atomicAdd(&scalars[0], dropped);
+    if (dropped && bin_lo == 0) atomicAdd(&scalars[0], dropped);
     if (LDS_HIST) {
         __syncthreads();
         // keep this block's histogram: bin_offsets_kernel turns it into the block's first slot per
         // bin, so the scatter pass needs neither a recount nor slot-reservation atomics
-        int32_t *mine = block_hist + (size_t)blockIdx.x * g.nbins;
-        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) {
+        int32_t *mine = block_hist + (size_t)blockIdx.x * g.nbins + bin_lo;
+        for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
             int c = hist[i];
             mine[i] = c;
-            if (c) atomicAdd(&bin_count[i], c);
+            if (c) atomicAdd(&bin_count[bin_lo + i], c);
         }
     }
 }
@@ -192,24 +195,25 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
                                                            const int32_t *__restrict__ bin_start,
                                                            int32_t *__restrict__ cursor,
                                                            const int32_t *__restrict__ block_hist,
-                                                           VisRec *__restrict__ recs)
+                                                           VisRec *__restrict__ recs, int bin_lo, int bin_hi)
 {
     extern __shared__ int32_t hist[];
     int64_t lo, hi;
     block_range(n, &lo, &hi);
     if (LDS_HIST) {
         // hist[bin] = this block's next free slot in the bin (its range was fixed by bin_offsets_kernel)
-        const int32_t *mine = block_hist + (size_t)blockIdx.x * g.nbins;
-        for (int i = threadIdx.x; i < g.nbins; i += blockDim.x) hist[i] = mine[i];
+        const int32_t *mine = block_hist + (size_t)blockIdx.x * g.nbins + bin_lo;
+        for (int i = threadIdx.x; i < bin_hi - bin_lo; i += blockDim.x) hist[i] = mine[i];
         __syncthreads();
     }
     // write the records
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
         if (b.bin < 0) continue;
+        if (LDS_HIST && (b.bin < bin_lo || b.bin >= bin_hi)) continue;
         int slot;
         if (LDS_HIST)
-            slot = atomicAdd(&hist[b.bin], 1);
+            slot = atomicAdd(&hist[b.bin - bin_lo], 1);
         else
             slot = bin_start[b.bin] + atomicAdd(&cursor[b.bin], 1);
         VisRec r;
@@ -231,8 +235,14 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.bin_count, 0, (size_t)g.nbins * sizeof(int32_t), ctx->stream));
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars, 0, 16 * sizeof(int32_t), ctx->stream));
 
-    const size_t hist_bytes = (size_t)g.nbins * sizeof(int32_t);
-    const bool lds_hist = hist_bytes <= (size_t)ctx->max_lds - 8192;
+    // The histogram of one launch lives in LDS; when there are more bins than fit (large grids x 8
+    // w-groups) the bins are covered in several windows, each a full sweep of the stream.  Beyond 8
+    // windows the re-reads cost more than plain global atomics.
+    const int cap = (int)(((size_t)ctx->max_lds - 8192) / sizeof(int32_t));
+    const int windows = (g.nbins + cap - 1) / cap;
+    const bool lds_hist = windows <= 8;
+    const int win = lds_hist ? (g.nbins + windows - 1) / windows : g.nbins;
+    const size_t hist_bytes = (size_t)win * sizeof(int32_t);
     const int threads = 1024;
     // one block per CU with an LDS histogram; more, smaller slices when counting in global memory
     int blocks = lds_hist ? ctx->num_cu * (hist_bytes <= 64 * 1024 ? 2 : 1) : ctx->num_cu * 8;
@@ -252,22 +262,29 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
             ctx->attr_mask |= 1u;
         }
-        hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
-                           v, uv_stride, wbin, t.bin_count, block_hist, t.scalars);
+        for (int wdw = 0; wdw < windows; ++wdw) {
+            const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
+            hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
+                               v, uv_stride, wbin, t.bin_count, block_hist, t.scalars, b_lo, b_hi);
+        }
     } else {
         hipLaunchKernelGGL(bin_count_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_count, block_hist, t.scalars);
+                           uv_stride, wbin, t.bin_count, block_hist, t.scalars, 0, g.nbins);
     }
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                        t.work_start, t.cursor);
     if (lds_hist) {
         hipLaunchKernelGGL(bin_offsets_kernel, dim3((g.nbins + 255) / 256), dim3(256), 0, ctx->stream, g.nbins, blocks,
                            t.bin_start, block_hist);
-        hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n,
-                           u, v, uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr);
+        for (int wdw = 0; wdw < windows; ++wdw) {
+            const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
+            hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n,
+                               u, v, uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr,
+                               b_lo, b_hi);
+        }
     } else
         hipLaunchKernelGGL(bin_scatter_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr);
+                           uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr, 0, g.nbins);
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }

@@ -92,6 +92,23 @@ def test_sorted_variant_matches_oracle(ctx, oracle, dist):
         assert rel(got, ref) < TOL
 
 
+@pytest.mark.parametrize("opts", [{"tile": 16, "wgroups": 4}, {"tile": 16, "wgroups": 8}, {"tile": 8, "wgroups": 8}])
+def test_many_bins_windowed_prepass(ctx, oracle, opts):
+    """More bins than one LDS histogram holds: the pre-pass covers them in windows (2 and 4 windows here),
+    and past 8 windows counts in global memory (the 8x8-tile case)."""
+    N, W, Q, S, n = 2048, 8, 2, 7, 300000
+    gcf, u, v, wb, vis = case(31, N, N, W, Q, S, S, n, spread=0.5)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+    try:
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+    finally:
+        for k in opts:
+            ctx.set_option(k, 0)
+    assert rel(got, ref) < TOL
+
+
 def test_direct_variant_matches_oracle(ctx, oracle):
     N, W, Q, S, n = 128, 4, 4, 7, 20000
     gcf, u, v, wb, vis = case(5, N, N, W, Q, S, S, n)
