@@ -21,6 +21,7 @@ ap.add_argument("--dist", default="uniform")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--wplanes", type=int, default=0)
 ap.add_argument("--grid", type=int, default=0)
+ap.add_argument("--support", type=int, default=0)
 ap.add_argument("sets", nargs="*")
 a = ap.parse_args()
 n, N, W, Q, S = bench.WORKLOADS[a.workload]
@@ -30,6 +31,8 @@ if a.wplanes:
     W = a.wplanes
 if a.grid:
     N = a.grid
+if a.support:
+    S = a.support
 dev = torch.device("cuda:0")
 ctx = gridhip.Context(0)
 gcf = bench.synth_kernels(W, Q, S, dev)
