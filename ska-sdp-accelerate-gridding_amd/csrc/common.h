@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <unordered_set>
 
 #include "../../include/gridhip.h"
 
@@ -68,7 +69,8 @@ struct gridhip_ctx {
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
-    uint32_t attr_mask = 0;  // which kernels already had their dynamic-LDS limit raised
+    uint32_t attr_mask = 0;  // pre-pass kernels whose dynamic-LDS limit has been raised
+    std::unordered_set<const void *> lds_raised;  // tile kernels whose dynamic-LDS limit has been raised
     void *fft_plan = nullptr;  // cached hipFFT Z2Z plan (imaging.hip)
     int64_t fft_n = 0;
 };

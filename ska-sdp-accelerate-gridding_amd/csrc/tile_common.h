@@ -81,12 +81,12 @@ static inline int work_blocks(const Geom &g, int64_t n)
 }
 
 template <typename K>
-static int raise_lds(gridhip_ctx *ctx, K kernel, uint32_t bit)
+static int raise_lds(gridhip_ctx *ctx, K kernel)
 {
-    if (ctx->attr_mask & bit) return GRIDHIP_OK;
-    GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          ctx->max_lds));
-    ctx->attr_mask |= bit;
+    const void *f = (const void *)kernel;
+    if (ctx->lds_raised.count(f)) return GRIDHIP_OK;
+    GH_CHECK_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+    ctx->lds_raised.insert(f);
     return GRIDHIP_OK;
 }
 

@@ -236,33 +236,29 @@ int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_byte
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
-#define GH_LAUNCH(S_, D_, BIT_)                                                                             \
+#define GH_LAUNCH(S_, D_)                                                                                   \
     do {                                                                                                    \
-        GH_CHECK(raise_lds(ctx, tile_grid_kernel<S_, D_>, BIT_));                                           \
+        GH_CHECK(raise_lds(ctx, tile_grid_kernel<S_, D_>));                                                 \
         hipLaunchKernelGGL((tile_grid_kernel<S_, D_>), gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start, \
                            t.work_start, (const double2 *)gcf, (const double2 *)vis, grid);                 \
     } while (0)
-    if (g.gh == 15 && g.gw == 15) {
-        if (g.dbg == 1)
-            GH_LAUNCH(15, 1, 1u << 16);
-        else if (g.dbg == 2)
-            GH_LAUNCH(15, 2, 1u << 17);
-        else if (g.dbg == 3)
-            GH_LAUNCH(15, 3, 1u << 18);
-        else
-            GH_LAUNCH(15, 0, 1u << 2);
-    } else if (g.gh == g.gw && g.gh == 5)
-        GH_LAUNCH(5, 0, 1u << 5);
-    else if (g.gh == g.gw && g.gh == 7)
-        GH_LAUNCH(7, 0, 1u << 3);
-    else if (g.gh == g.gw && g.gh == 9)
-        GH_LAUNCH(9, 0, 1u << 6);
-    else if (g.gh == g.gw && g.gh == 11)
-        GH_LAUNCH(11, 0, 1u << 7);
-    else if (g.gh == g.gw && g.gh == 13)
-        GH_LAUNCH(13, 0, 1u << 8);
+#define GH_CASE(S_) \
+    case S_: GH_LAUNCH(S_, 0); break;
+    if (g.gh == 15 && g.gw == 15 && g.dbg == 1)
+        GH_LAUNCH(15, 1);
+    else if (g.gh == 15 && g.gw == 15 && g.dbg == 2)
+        GH_LAUNCH(15, 2);
+    else if (g.gh == 15 && g.gw == 15 && g.dbg == 3)
+        GH_LAUNCH(15, 3);
+    else if (g.gh == g.gw)
+        switch (g.gh) {
+            GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)
+            GH_CASE(14) GH_CASE(15) GH_CASE(16)
+            default: GH_LAUNCH(0, 0);
+        }
     else
-        GH_LAUNCH(0, 0, 1u << 4);
+        GH_LAUNCH(0, 0);
+#undef GH_CASE
 #undef GH_LAUNCH
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
@@ -274,7 +270,7 @@ int launch_tile_degrid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_by
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
-    GH_CHECK(raise_lds(ctx, tile_degrid_kernel, 1u << 10));
+    GH_CHECK(raise_lds(ctx, tile_degrid_kernel));
     hipLaunchKernelGGL(tile_degrid_kernel, gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start, t.work_start,
                        (const double2 *)gcf, (const double2 *)grid, (double2 *)vis_out);
     GH_CHECK_HIP(ctx, hipGetLastError());

@@ -280,8 +280,8 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
 // staged records.  On success returns the LDS bytes and the batch size.
 bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, int *batch, size_t *lds_bytes)
 {
-    // square odd supports with a compile-time instantiation below
-    if (g.gh != g.gw || g.gh < 5 || g.gh > 15 || !(g.gh & 1)) return false;
+    // square supports with a compile-time instantiation below
+    if (g.gh != g.gw || g.gh < 5 || g.gh > 16) return false;
     if (g.per_vis || g.T > 128) return false;
     const int planes = (g.W + g.ngroups - 1) / g.ngroups + 1;  // groups differ by at most one plane
     const int64_t keys = (int64_t)planes * g.Q * g.Q;
@@ -306,29 +306,26 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
-#define GH_LAUNCH(S_, D_, BIT_)                                                                                  \
+#define GH_LAUNCH(S_, D_)                                                                                        \
     do {                                                                                                         \
-        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_>, BIT_));                                         \
+        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_>));                                               \
         hipLaunchKernelGGL((tile_grid_sorted_kernel<S_, D_>), gr, bl, lds_bytes, ctx->stream, g, recs,           \
                            t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
                            t.scalars);                                                                           \
     } while (0)
-    // attr_mask bits 20..31: one per instantiation
-    switch (g.gh * 2 + (degrid ? 1 : 0)) {
-        case 5 * 2: GH_LAUNCH(5, false, 1u << 20); break;
-        case 5 * 2 + 1: GH_LAUNCH(5, true, 1u << 21); break;
-        case 7 * 2: GH_LAUNCH(7, false, 1u << 22); break;
-        case 7 * 2 + 1: GH_LAUNCH(7, true, 1u << 23); break;
-        case 9 * 2: GH_LAUNCH(9, false, 1u << 24); break;
-        case 9 * 2 + 1: GH_LAUNCH(9, true, 1u << 25); break;
-        case 11 * 2: GH_LAUNCH(11, false, 1u << 26); break;
-        case 11 * 2 + 1: GH_LAUNCH(11, true, 1u << 27); break;
-        case 13 * 2: GH_LAUNCH(13, false, 1u << 28); break;
-        case 13 * 2 + 1: GH_LAUNCH(13, true, 1u << 29); break;
-        case 15 * 2: GH_LAUNCH(15, false, 1u << 30); break;
-        case 15 * 2 + 1: GH_LAUNCH(15, true, 1u << 31); break;
+#define GH_CASE(S_)             \
+    case S_:                    \
+        if (degrid)             \
+            GH_LAUNCH(S_, true); \
+        else                    \
+            GH_LAUNCH(S_, false); \
+        break;
+    switch (g.gh) {
+        GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)
+        GH_CASE(14) GH_CASE(15) GH_CASE(16)
         default: return fail(ctx, GRIDHIP_EUNSUPPORTED, "no sorted instantiation for support %d", g.gh);
     }
+#undef GH_CASE
 #undef GH_LAUNCH
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;

@@ -47,6 +47,9 @@ SHAPES = [
     (160, 160, 4, 4, 11, 11, 20000),
     (160, 160, 4, 2, 13, 13, 20000),
     (160, 160, 4, 4, 5, 5, 20000),
+    (160, 160, 4, 2, 6, 6, 20000),      # even supports have instantiations too
+    (160, 160, 4, 2, 12, 12, 20000),
+    (160, 160, 2, 2, 16, 16, 20000),
 ]
 
 
@@ -81,7 +84,8 @@ def test_tuning_knobs_do_not_change_results(ctx, oracle, tile, block, wgroups, c
 def test_sorted_variant_matches_oracle(ctx, oracle, dist):
     """The tap-reusing kernel (records sorted by kernel slice in LDS, runs share registers)."""
     for (N, W, Q, S, n) in [(512, 32, 8, 15, 150000), (300, 16, 4, 7, 80000), (256, 8, 4, 9, 60000),
-                            (256, 8, 4, 11, 60000), (256, 8, 2, 13, 60000), (200, 4, 4, 5, 50000)]:
+                            (256, 8, 4, 11, 60000), (256, 8, 2, 13, 60000), (200, 4, 4, 5, 50000),
+                            (256, 8, 2, 8, 60000), (256, 8, 2, 14, 60000), (256, 4, 2, 16, 60000)]:
         gcf, u, v, wb, vis = case(7 + N, N, N, W, Q, S, S, n, dist=dist)
         ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
         ctx.set_option("sort", 1)
