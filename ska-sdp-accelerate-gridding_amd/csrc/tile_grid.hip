@@ -129,26 +129,46 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
             }
         }
     } else {
+        // general shape: the taps of the next 64-tap step (and, at a visibility's last step, the first
+        // step of the next visibility) are in flight while the current step is accumulated; loads are
+        // unconditional (indices clamped), only the adds are predicated.
         const int dj = 64 % gw, di = 64 / gw;
-        for (int vi = w.v_lo + wave; vi < w.v_hi; vi += nw) {
-            const VisRec r = load_rec(recs, vi);
-            const double2 val = vis[r.orig];
-            const double2 *kp = gcf + (size_t)r.kslice * S2;
-            const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);
-            int i = lane / gw, j = lane - i * gw;
-            for (int t = lane; t < S2; t += 64) {
-                const double2 kv = kp[t];
-                const double re = val.x * kv.x - val.y * kv.y;
-                const double im = val.x * kv.y + val.y * kv.x;
-                const int a = lbase + i * g.ldw + j;
-                __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                j += dj;
-                i += di;
-                if (j >= gw) {
-                    j -= gw;
-                    ++i;
+        const int nstep = (S2 + 63) >> 6;
+        const int last = w.v_hi - 1;
+        int vi = w.v_lo + wave;
+        if (vi <= last) {
+            VisRec r = load_rec(recs, vi);
+            VisRec rn = load_rec(recs, min(vi + nw, last));
+            double2 val = vis[r.orig];
+            double2 kv_next = gcf[(size_t)r.kslice * S2 + min(lane, S2 - 1)];
+            for (; vi <= last; vi += nw) {
+                const VisRec rnn = load_rec(recs, min(vi + 2 * nw, last));
+                const double2 valn = vis[rn.orig];
+                const double2 *kp = gcf + (size_t)r.kslice * S2;
+                const double2 *kpn = gcf + (size_t)rn.kslice * S2;
+                const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);
+                int i = lane / gw, j = lane - i * gw;
+                for (int s = 0; s < nstep; ++s) {
+                    const int t = s * 64 + lane;
+                    const double2 kv = kv_next;
+                    kv_next = (s + 1 < nstep) ? kp[min(t + 64, S2 - 1)] : kpn[min(lane, S2 - 1)];
+                    if (t < S2) {
+                        const double re = val.x * kv.x - val.y * kv.y;
+                        const double im = val.x * kv.y + val.y * kv.x;
+                        const int a = lbase + i * g.ldw + j;
+                        __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    j += dj;
+                    i += di;
+                    if (j >= gw) {
+                        j -= gw;
+                        ++i;
+                    }
                 }
+                r = rn;
+                rn = rnn;
+                val = valn;
             }
         }
     }
@@ -205,28 +225,43 @@ __global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec 
     const int gw = g.gw, S2 = g.gh * g.gw;
     const int dj = 64 % gw, di = 64 / gw;
 
-    for (int vi = w.v_lo + wave; vi < w.v_hi; vi += nw) {
-        const VisRec r = load_rec(recs, vi);
-        const double2 *kp = gcf + (size_t)r.kslice * S2;
-        const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);
-        double sr = 0.0, si = 0.0;
-        int i = lane / gw, j = lane - i * gw;
-        for (int t = lane; t < S2; t += 64) {
-            const double2 kv = kp[t];
-            const int a = lbase + i * g.ldw + j;
-            const double gr = lre[a], gi = lim[a];
-            sr += kv.x * gr - kv.y * gi;
-            si += kv.x * gi + kv.y * gr;
-            j += dj;
-            i += di;
-            if (j >= gw) {
-                j -= gw;
-                ++i;
+    const int nstep = (S2 + 63) >> 6;
+    const int last = w.v_hi - 1;
+    int vi = w.v_lo + wave;
+    if (vi <= last) {
+        VisRec r = load_rec(recs, vi);
+        VisRec rn = load_rec(recs, min(vi + nw, last));
+        double2 kv_next = gcf[(size_t)r.kslice * S2 + min(lane, S2 - 1)];
+        for (; vi <= last; vi += nw) {
+            const VisRec rnn = load_rec(recs, min(vi + 2 * nw, last));
+            const double2 *kp = gcf + (size_t)r.kslice * S2;
+            const double2 *kpn = gcf + (size_t)rn.kslice * S2;
+            const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);
+            double sr = 0.0, si = 0.0;
+            int i = lane / gw, j = lane - i * gw;
+            for (int s = 0; s < nstep; ++s) {
+                const int t = s * 64 + lane;
+                const double2 kv = kv_next;
+                kv_next = (s + 1 < nstep) ? kp[min(t + 64, S2 - 1)] : kpn[min(lane, S2 - 1)];
+                if (t < S2) {
+                    const int a = lbase + i * g.ldw + j;
+                    const double gr = lre[a], gi = lim[a];
+                    sr += kv.x * gr - kv.y * gi;
+                    si += kv.x * gi + kv.y * gr;
+                }
+                j += dj;
+                i += di;
+                if (j >= gw) {
+                    j -= gw;
+                    ++i;
+                }
             }
+            sr = wave_sum_lane63(sr);
+            si = wave_sum_lane63(si);
+            if (lane == 63) vis_out[r.orig] = make_double2(sr, si);
+            r = rn;
+            rn = rnn;
         }
-        sr = wave_sum_lane63(sr);
-        si = wave_sum_lane63(si);
-        if (lane == 63) vis_out[r.orig] = make_double2(sr, si);
     }
 }
 
