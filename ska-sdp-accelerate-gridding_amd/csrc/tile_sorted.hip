@@ -167,6 +167,10 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                 uint32_t m = meta[min(q0, seg_hi - 1)];
                 if (!DEGRID) {
                     double2 v = vals[min(q0, seg_hi - 1)];
+                    // Consume the two reads here: otherwise their wait lands in the loop header, where it
+                    // merges with the back edge into lgkmcnt(0) and every trip would drain the previous
+                    // visibility's eight ds_add_f64 before starting (checked in the ISA).
+                    asm volatile("" ::"v"(m), "v"(v.x), "v"(v.y));
                     for (int i = 0; i < len; ++i) {
                         const int qn = min(q0 + i + 1, seg_hi - 1);
                         const uint32_t mn = meta[qn];  // next record's LDS reads go out before this one's atomics
@@ -190,6 +194,7 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                 } else {
                     const int32_t *origs = reinterpret_cast<const int32_t *>(vals);
                     int32_t o = origs[min(q0, seg_hi - 1)];
+                    asm volatile("" ::"v"(m), "v"(o));  // same reason as above
                     for (int i = 0; i < len; ++i) {
                         const int qn = min(q0 + i + 1, seg_hi - 1);
                         const uint32_t mn = meta[qn];
