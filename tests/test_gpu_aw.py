@@ -26,7 +26,8 @@ def test_smalltest_aw_fixture(ctx, golden):
     assert np.abs(G3 - G).max() <= 1e-15 * np.abs(G).max()
 
 
-@pytest.mark.parametrize("N,W,Q,S,A,n", [(64, 3, 2, 15, 6, 300), (96, 2, 4, 7, 12, 500), (80, 4, 1, 9, 3, 200)])
+@pytest.mark.parametrize("N,W,Q,S,A,n", [(64, 3, 2, 15, 6, 300), (96, 2, 4, 7, 12, 500), (80, 4, 1, 9, 3, 200),
+                                         (72, 2, 2, 16, 4, 150), (90, 2, 2, 19, 3, 60), (64, 2, 2, 4, 5, 300)])
 def test_awgrid_matches_oracle(ctx, oracle, N, W, Q, S, A, n):
     rng = np.random.default_rng(N + S)
     wk = rng.normal(size=(W, Q, Q, S, S)) + 1j * rng.normal(size=(W, Q, Q, S, S))
