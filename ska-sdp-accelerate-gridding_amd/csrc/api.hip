@@ -1,6 +1,5 @@
 // C-ABI entry points of the gridders (include/gridhip.h): argument checks, the device-pointer
 // forms that enqueue the kernels, and the host-pointer drop-in forms that stage through HBM.
-#include <vector>
 
 #include "common.h"
 

@@ -8,7 +8,6 @@
 #include <math.h>
 #include <string.h>
 
-#include <vector>
 
 #include "common.h"
 
