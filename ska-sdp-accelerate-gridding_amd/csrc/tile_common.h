@@ -11,11 +11,9 @@ struct WorkItem {
 // Map blockIdx -> work item.  Work items of w-group g are the blocks with blockIdx % ngroups
 // == g, so with the dispatcher's round-robin over the 8 XCDs a group's kernel planes stay in
 // one XCD's L2 (speed only; any placement is correct).
-__device__ __forceinline__ bool find_work(const Geom &g, const int32_t *__restrict__ bin_start,
-                                          const int32_t *__restrict__ work_start, WorkItem *w)
+__device__ __forceinline__ bool find_work_at(const Geom &g, const int32_t *__restrict__ bin_start,
+                                             const int32_t *__restrict__ work_start, int grp, int k, WorkItem *w)
 {
-    const int grp = blockIdx.x % g.ngroups;
-    const int k = blockIdx.x / g.ngroups;
     const int32_t *ws = work_start + (size_t)grp * (g.ntiles + 1);
     if (k >= ws[g.ntiles]) return false;
     int lo = 0, hi = g.ntiles;  // largest t with ws[t] <= k
@@ -33,6 +31,12 @@ __device__ __forceinline__ bool find_work(const Geom &g, const int32_t *__restri
     w->v_lo = b0 + (int)(((int64_t)cnt * c) / nch);
     w->v_hi = b0 + (int)(((int64_t)cnt * (c + 1)) / nch);
     return true;
+}
+
+__device__ __forceinline__ bool find_work(const Geom &g, const int32_t *__restrict__ bin_start,
+                                          const int32_t *__restrict__ work_start, WorkItem *w)
+{
+    return find_work_at(g, bin_start, work_start, blockIdx.x % g.ngroups, blockIdx.x / g.ngroups, w);
 }
 
 // All lanes of the wave read the same 16 bytes (one broadcast transaction).  Vector loads on

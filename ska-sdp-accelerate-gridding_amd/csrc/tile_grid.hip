@@ -178,15 +178,17 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
     const int tx = w.tile % g.ntx, ty = w.tile / g.ntx;
     const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
     const int ncell = g.lrows * g.lcols;
-    for (int c = tid; c < ncell; c += blockDim.x) {
+    // Consecutive lanes take (re, im) of consecutive cells, so one atomic instruction covers a
+    // contiguous 512-byte run of the interleaved grid row (memory-side fp64 atomics run at full rate
+    // on contiguous runs and at half of it on the stride-16 pattern of one component at a time).
+    for (int e = tid; e < 2 * ncell; e += blockDim.x) {
+        const int c = e >> 1, comp = e & 1;
         const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
         const int64_t gx = ox + c_, gy = oy + r_;
         if (gx < 0 || gy < 0 || gx >= g.Wd || gy >= g.H) continue;
-        const double re = lre[r_ * g.ldw + c_], im = lim[r_ * g.ldw + c_];
-        if (re == 0.0 && im == 0.0) continue;
-        double *dst = grid + 2 * (gy * g.Wd + gx);
-        unsafeAtomicAdd(dst, re);
-        unsafeAtomicAdd(dst + 1, im);
+        const double val = comp ? lim[r_ * g.ldw + c_] : lre[r_ * g.ldw + c_];
+        if (val == 0.0) continue;
+        unsafeAtomicAdd(grid + 2 * (gy * g.Wd + gx) + comp, val);
     }
 }
 

@@ -29,9 +29,6 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                                                                 int32_t *__restrict__ scalars)
 {
     extern __shared__ double lds[];
-    WorkItem w;
-    if (!find_work(g, bin_start, work_start, &w)) return;
-
     constexpr int S2 = S * S;
     constexpr int NSTEP = (S2 + 63) / 64;
     constexpr int TAIL = S2 - (NSTEP - 1) * 64;
@@ -45,8 +42,24 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
     double2 *vals = reinterpret_cast<double2 *>(hist + hist_words);
     uint32_t *meta = reinterpret_cast<uint32_t *>(vals + batch);
     int32_t *wsum = reinterpret_cast<int32_t *>(vals);  // per-wave totals of the scan (before vals is filled)
+    int32_t *s_item = reinterpret_cast<int32_t *>(meta + batch);  // 16 B past the staging (sorted_plan)
 
-    const int grp = blockIdx.x % g.ngroups;
+    // Persistent work-groups: the launch has one work-group per CU slot; each pulls work items of
+    // "its" w-group (blockIdx % ngroups: the group whose kernel planes this XCD's L2 holds) from a
+    // queue counter, then helps the other groups when its own queue is empty.  Every wave leaves
+    // the loop once all queues are exhausted; there is no waiting on other work-groups.
+    int32_t *queue = scalars + 4;
+    for (int turn = 0; turn < g.ngroups;) {
+    const int grp = (blockIdx.x + turn) % g.ngroups;
+    if (tid == 0) *s_item = atomicAdd(&queue[grp], 1);
+    __syncthreads();
+    const int item = *s_item;
+    __syncthreads();
+    WorkItem w;
+    if (!find_work_at(g, bin_start, work_start, grp, item, &w)) {
+        ++turn;  // this group's queue is exhausted (uniform across the work-group)
+        continue;
+    }
     const int first_plane = (grp * g.W + g.ngroups - 1) / g.ngroups;  // smallest wb with wb*ng/W == grp
     const int first_slice = first_plane * g.Q * g.Q;
 
@@ -264,20 +277,24 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             process(kB, q, 0);
         }
     }
-    if (DEGRID) return;
-    __syncthreads();
+    __syncthreads();  // all waves done with the tile (and with this item's staging)
+    if (DEGRID) continue;
 
     // ---- flush the cells that exist in the grid
-    for (int c = tid; c < ncell; c += nthr) {
+    // Consecutive lanes take (re, im) of consecutive cells, so one atomic instruction covers a
+    // contiguous 512-byte run of the interleaved grid row (memory-side fp64 atomics run at full rate
+    // on contiguous runs and at half of it on the stride-16 pattern of one component at a time).
+    for (int e = tid; e < 2 * ncell; e += nthr) {
+        const int c = e >> 1, comp = e & 1;
         const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
         const int64_t gx = ox + c_, gy = oy + r_;
         if (gx < 0 || gy < 0 || gx >= g.Wd || gy >= g.H) continue;
-        const double re = lre[r_ * g.ldw + c_], im = lim[r_ * g.ldw + c_];
-        if (re == 0.0 && im == 0.0) continue;
-        double *dst = grid + 2 * (gy * g.Wd + gx);
-        unsafeAtomicAdd(dst, re);
-        unsafeAtomicAdd(dst + 1, im);
+        const double val = comp ? lim[r_ * g.ldw + c_] : lre[r_ * g.ldw + c_];
+        if (val == 0.0) continue;
+        unsafeAtomicAdd(grid + 2 * (gy * g.Wd + gx) + comp, val);
     }
+    __syncthreads();  // the tile is re-initialised by the next work item
+    }  // persistent loop
 }
 
 // Can the sorted variant run this geometry?  Needs a compile-time support, the per-group slice
@@ -294,14 +311,14 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     const size_t tile = (size_t)g.lrows * g.ldw * 16;
     const size_t hist = (size_t)((keys + 1 + 3) & ~3) * 4;
     if (tile + hist + 512 * 20 + 512 > (size_t)ctx->max_lds) return false;
-    int c = (int)(((size_t)ctx->max_lds - 512 - tile - hist) / 20);
+    int c = (int)(((size_t)ctx->max_lds - 1024 - tile - hist) / 20);
     (void)block;
     c &= ~63;
     if (c > 8192) c = 8192;
     if (c < 512) return false;
     *nkeys = (int)keys;
     *batch = c;
-    *lds_bytes = tile + hist + (size_t)c * 20;
+    *lds_bytes = tile + hist + (size_t)c * 20 + 16;  // + the work-queue slot
     return true;
 }
 
@@ -310,7 +327,16 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
 {
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
-    const dim3 gr(work_blocks(g, n)), bl(block);
+    // persistent work-groups: as many as can be resident (LDS-limited), pulling items from per-group queues
+    int per_cu = (int)((size_t)ctx->max_lds / lds_bytes);
+    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+    if (per_cu * block > 2048) per_cu = 2048 / block > 0 ? 2048 / block : 1;
+    int nblk = ctx->num_cu * per_cu;
+    nblk = ((nblk + g.ngroups - 1) / g.ngroups) * g.ngroups;
+    const int most = work_blocks(g, n);
+    if (nblk > most) nblk = most > g.ngroups ? (most / g.ngroups) * g.ngroups : g.ngroups;
+    const dim3 gr(nblk), bl(block);
+    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 4, 0, 8 * sizeof(int32_t), ctx->stream));
 #define GH_LAUNCH(S_, D_)                                                                                        \
     do {                                                                                                         \
         GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_>));                                               \
