@@ -94,7 +94,7 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
     const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)g.nbins >= 256);
     const bool sorted = want_sort && sorted_plan(ctx, g, block, &nkeys, &maxchunk, &lds_sorted);
     // a sorted work item may span several LDS batches; keep it big enough to flush each tile once
-    if (sorted && ctx->opt.chunk == 0) g.chunk = 4 * maxchunk;
+    if (sorted) g.chunk = maxchunk;
     // scratch is sized before the timed region begins
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
@@ -136,7 +136,7 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     size_t lds_sorted = 0;
     const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)g.nbins >= 256);
     const bool sorted = want_sort && sorted_plan(ctx, g, block, &nkeys, &batch, &lds_sorted);
-    if (sorted && ctx->opt.chunk == 0) g.chunk = 4 * batch;
+    if (sorted) g.chunk = batch;
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
     mark(ctx, 0);

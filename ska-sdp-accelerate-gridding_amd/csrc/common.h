@@ -62,6 +62,7 @@ struct gridhip_ctx {
     gridhip::Workspace recs;    // VisRec[n]
     gridhip::Workspace tables;  // bin_count / bin_start / work_start / cursors / scalars
     gridhip::Workspace stage;   // staging for the host-pointer entry points
+    gridhip::Workspace sorted;  // sorted-list scratch of the tap-reusing tile kernel (tile_sorted.hip)
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
     int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=last call's n; 16 ints
     int num_cu = 256;

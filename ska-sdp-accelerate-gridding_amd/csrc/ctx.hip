@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gridhip {
@@ -212,8 +214,8 @@ int gridhip_create(int device, gridhip_ctx **out)
         return GRIDHIP_EHIP;
     }
     ctx->stream = ctx->own_stream;
-    if (hipMalloc((void **)&ctx->d_scalars, 16 * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(ctx->d_scalars, 0, 16 * sizeof(int32_t)) != hipSuccess) {
+    if (hipMalloc((void **)&ctx->d_scalars, 128 * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(ctx->d_scalars, 0, 128 * sizeof(int32_t)) != hipSuccess) {
         gridhip_destroy(ctx);
         return GRIDHIP_ENOMEM;
     }
@@ -232,7 +234,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     fft_release(ctx);
-    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist};
+    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -301,6 +303,19 @@ int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value)
         GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
         int32_t h = 0;
         GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_scalars + 2, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *value = h;
+        return GRIDHIP_OK;
+    }
+    if (!strncmp(key, "prof", 4) && key[4] >= '0' && key[4] <= '9') {
+        // read-only: cycles summed over work-groups by a dbg=16 tuning launch of the sorted kernel
+        // (0..6: per phase, thread 0; 8..23: the accumulate walk of wave 0..15)
+        const int slot = atoi(key + 4);
+        if (slot < 0 || slot >= 32) return fail(ctx, GRIDHIP_EINVAL, "unknown option '%s'", key);
+        GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+        int64_t h = 0;
+        GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_scalars + 32 + 2 * slot, sizeof h, hipMemcpyDeviceToHost,
+                                         ctx->stream));
         GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         *value = h;
         return GRIDHIP_OK;

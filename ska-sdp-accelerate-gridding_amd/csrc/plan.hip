@@ -63,7 +63,7 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
     }
     const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)p->g.nbins >= 256);
     p->sorted = want_sort && sorted_plan(ctx, p->g, p->block, &p->nkeys, &p->batch, &p->lds_sorted);
-    if (p->sorted && ctx->opt.chunk == 0) p->g.chunk = 4 * p->batch;
+    if (p->sorted) p->g.chunk = p->batch;
     {
         Lend lend(p);
         rc = ws_reserve(ctx, ctx->tables, tables_bytes(p->g));

@@ -2,53 +2,76 @@
 //
 // The plain tile kernel streams one [S][S] kernel slice (3.6 KB at 15x15) from L2 for every
 // visibility; at 10^8 visibilities that L2->CU stream (360 GB) is what bounds it.  Within one
-// work item (w-group x tile, <= ~3000 visibilities) only ~1000 distinct slices occur, so this
-// variant first orders the work item's records by slice inside LDS (counting sort: histogram,
-// scan, scatter) and stages the visibility values next to them; each wave then walks a
-// contiguous piece of the sorted list run by run, keeping a run's taps in registers and fetching
-// the next run's taps while the current run is accumulated.  Tap traffic drops by the mean run
-// length (~3x on the uniform benchmark; far more on real, w-coherent data).
+// work item (w-group x tile, ~3000 visibilities) only ~1000 distinct slices occur, so this
+// variant first orders the work item's records by slice (counting sort: LDS histogram, scan,
+// scatter) and each wave then walks a contiguous piece of the sorted list run by run, keeping a
+// run's taps in registers and fetching the next runs' taps while the current run is accumulated.
+// Tap traffic drops by the mean run length (~3x on the uniform benchmark; far more on real,
+// w-coherent data).
 //
-// LDS plan (T=64, 15x15): tile 98.6 KB | histogram 4.4 KB | values 16 B x batch | meta 4 B x batch
-// (batch = 3008).  The tile stays resident for the whole work item (flushed once); the work item's
-// records pass through in batches.
+// Where things live (T=64, 15x15): LDS holds the tile (98.6 KB, resident for the whole work item,
+// flushed once) and the sort's histogram (4.1 KB).  The sorted list itself - per record the
+// visibility value (16 B) and (meta, orig) (8 B) - goes to a per-work-group scratch in global
+// memory: it is written once and read once, coalesced, by the same CU (L2-resident), which keeps
+// LDS reads out of the accumulate loop altogether: an LDS read returns only after the wave's
+// outstanding ds_add_f64s, so every read there would drain the atomic queue.
 #include "tile_common.h"
 
 namespace gridhip {
 
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                            __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
 // DEGRID = false: accumulate vis * taps into the tile and flush it onto `grid` (convgrid2).
 // DEGRID = true : the tile is loaded from `grid` once and each visibility's sum over taps of
 //                 taps * tile is written to vis_out[orig] (degrid2); `vis` is then the output.
-template <int S, bool DEGRID>
+// ABL (tuning runs only, option "dbg"): bit 0 = no LDS atomics in the accumulate loop, bit 1 = no flush,
+// bit 2 = no tap loads, bit 3 = no visibility gather, bit 4 = per-phase cycle stamps.  Results are wrong
+// with any of bits 0..3 set.
+template <int S, bool DEGRID, int ABL = 0>
 __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
                                                                 const int32_t *__restrict__ work_start,
                                                                 const double2 *__restrict__ gcf,
                                                                 double2 *__restrict__ vis,
                                                                 double *__restrict__ grid, int nkeys, int batch,
-                                                                int32_t *__restrict__ scalars)
+                                                                int32_t *__restrict__ scalars,
+                                                                double2 *__restrict__ sorted_vals,
+                                                                uint2 *__restrict__ sorted_mo)
 {
     extern __shared__ double lds[];
     constexpr int S2 = S * S;
     constexpr int NSTEP = (S2 + 63) / 64;
     constexpr int TAIL = S2 - (NSTEP - 1) * 64;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int plane = g.lrows * g.ldw;
-    // LDS: tile (re plane, im plane) | histogram | staged values | staged meta
+    // LDS: tile (re plane, im plane) | histogram | per-wave scan totals, work-queue slot
     double *lre = lds, *lim = lds + plane;
     int32_t *hist = reinterpret_cast<int32_t *>(lds + 2 * plane);
-    const int hist_words = (nkeys + 1 + 3) & ~3;  // keep what follows 16-byte aligned
-    double2 *vals = reinterpret_cast<double2 *>(hist + hist_words);
-    uint32_t *meta = reinterpret_cast<uint32_t *>(vals + batch);
-    int32_t *wsum = reinterpret_cast<int32_t *>(vals);  // per-wave totals of the scan (before vals is filled)
-    int32_t *s_item = reinterpret_cast<int32_t *>(meta + batch);  // 16 B past the staging (sorted_plan)
+    const int hist_words = (nkeys + 1 + 3) & ~3;
+    int32_t *wsum = hist + hist_words;  // [16]
+    int32_t *s_item = wsum + 16;
+    // this work-group's slice of the sorted-list scratch
+    double2 *svals = sorted_vals + (size_t)blockIdx.x * batch;
+    uint2 *smo = sorted_mo + (size_t)blockIdx.x * batch;
 
     // Persistent work-groups: the launch has one work-group per CU slot; each pulls work items of
     // "its" w-group (blockIdx % ngroups: the group whose kernel planes this XCD's L2 holds) from a
     // queue counter, then helps the other groups when its own queue is empty.  Every wave leaves
     // the loop once all queues are exhausted; there is no waiting on other work-groups.
     int32_t *queue = scalars + 4;
+    long long prof[7] = {0, 0, 0, 0, 0, 0, 0}, pt = 0;  // ABL & 16: cycles per phase, thread 0
+#define GH_STAMP(i_)                        \
+    if ((ABL & 16) && tid == 0) {           \
+        const long long now_ = clock64();   \
+        prof[i_] += now_ - pt;              \
+        pt = now_;                          \
+    }
+    if ((ABL & 16) && tid == 0) pt = clock64();
     for (int turn = 0; turn < g.ngroups;) {
     const int grp = (blockIdx.x + turn) % g.ngroups;
     if (tid == 0) *s_item = atomicAdd(&queue[grp], 1);
@@ -91,128 +114,168 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
     }
     const int ttail = tail_ok ? (NSTEP - 1) * 64 + lane : 0;
 
-    // The tile stays in LDS for the whole work item; its records go through in batches that fit
-    // next to it.
-    for (int b_lo = w.v_lo; b_lo < w.v_hi; b_lo += batch) {
-        const int cnt = min(batch, w.v_hi - b_lo);
+    // a work item never holds more than `batch` records (the host sets chunk <= batch)
+    const int b_lo = w.v_lo;
+    const int cnt = min(batch, w.v_hi - b_lo);
 
-        // ---- counting sort of this batch's records by kernel slice ---------------------------
-        __syncthreads();  // previous batch fully consumed (and, first time, the tile zeroed)
-        for (int i = tid; i <= nkeys; i += nthr) hist[i] = 0;
-        __syncthreads();
-        for (int r = tid; r < cnt; r += nthr) {
-            const VisRec rec = load_rec(recs, b_lo + r);
-            const int key = rec.kslice - first_slice;
-            if ((unsigned)key < (unsigned)nkeys) atomicAdd(&hist[key], 1);
-        }
-        __syncthreads();
-        {   // exclusive scan of hist[0..nkeys): each thread owns a contiguous strip
-            const int per = (nkeys + nthr - 1) / nthr;
-            const int lo = min(tid * per, nkeys), hi = min(lo + per, nkeys);
-            int s = 0;
-            for (int i = lo; i < hi; ++i) s += hist[i];
-            int incl = s;  // inclusive scan across the wave
+    // ---- counting sort of the item's records by kernel slice ---------------------------------
+    GH_STAMP(0)  // work fetch, tile init
+    for (int i = tid; i <= nkeys; i += nthr) hist[i] = 0;
+    __syncthreads();
+    for (int r = tid; r < cnt; r += nthr) {
+        const VisRec rec = load_rec(recs, b_lo + r);
+        const int key = rec.kslice - first_slice;
+        if ((unsigned)key < (unsigned)nkeys) atomicAdd(&hist[key], 1);
+    }
+    __syncthreads();
+    GH_STAMP(1)  // histogram
+    {   // exclusive scan of hist[0..nkeys): each thread owns a contiguous strip
+        const int per = (nkeys + nthr - 1) / nthr;
+        const int lo = min(tid * per, nkeys), hi = min(lo + per, nkeys);
+        int s = 0;
+        for (int i = lo; i < hi; ++i) s += hist[i];
+        int incl = s;  // inclusive scan across the wave
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            int base = incl - s;
-            for (int ww = 0; ww < wave; ++ww) base += wsum[ww];
-            __syncthreads();  // wsum is about to be overwritten by vals
-            for (int i = lo; i < hi; ++i) {
-                const int c = hist[i];
-                hist[i] = base;
-                base += c;
-            }
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
         }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        int bad = 0;
-        for (int r = tid; r < cnt; r += nthr) {
-            const VisRec rec = load_rec(recs, b_lo + r);
-            const int key = rec.kslice - first_slice;
+        int base = incl - s;
+        for (int ww = 0; ww < wave; ++ww) base += wsum[ww];
+        for (int i = lo; i < hi; ++i) {
+            const int c = hist[i];
+            hist[i] = base;
+            base += c;
+        }
+    }
+    __syncthreads();
+    GH_STAMP(2)  // scan
+    int bad = 0;
+    // four records per thread and trip: their record loads, then their value gathers, are all in flight
+    // together (the gather is a dependent, HBM-random access; taken one record at a time its latency
+    // is the whole phase)
+    for (int r0 = tid; r0 < cnt; r0 += 4 * nthr) {
+        VisRec rec[4];
+        double2 val[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rec[q] = load_rec(recs, b_lo + min(r0 + q * nthr, cnt - 1));
+        if (!DEGRID) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) val[q] = (ABL & 8) ? make_double2(1.0, (double)q) : vis[rec[q].orig];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (r0 + q * nthr >= cnt) break;
+            const int key = rec[q].kslice - first_slice;
             if ((unsigned)key >= (unsigned)nkeys) {  // cannot happen unless binning and kernel disagree
                 ++bad;
                 continue;
             }
             const int pos = atomicAdd(&hist[key], 1);
             if ((unsigned)pos < (unsigned)batch) {
-                meta[pos] = ((uint32_t)key << 16) | (uint32_t)((rec.lxy >> 16) << 8) | (uint32_t)(rec.lxy & 0xff);
-                if (DEGRID)
-                    reinterpret_cast<int32_t *>(vals)[pos] = rec.orig;
-                else
-                    vals[pos] = vis[rec.orig];
+                smo[pos] = make_uint2(((uint32_t)key << 16) | (uint32_t)((rec[q].lxy >> 16) << 8) |
+                                          (uint32_t)(rec[q].lxy & 0xff),
+                                      (uint32_t)rec[q].orig);
+                if (!DEGRID) svals[pos] = val[q];
             } else
                 ++bad;
         }
-        if (bad) atomicAdd(&scalars[2], bad);
-        __syncthreads();
-        // records that were rejected leave holes at the end of the sorted list: hist[nkeys-1] is now
-        // the number actually staged
-        const int staged = hist[nkeys - 1];
+    }
+    if (bad) atomicAdd(&scalars[2], bad);
+    __syncthreads();  // (also makes the scratch writes visible to the work-group's other waves)
+    // records that were rejected leave holes at the end of the sorted list: hist[nkeys-1] is now
+    // the number actually staged
+    const int staged = hist[nkeys - 1];
+    GH_STAMP(3)  // scatter + value gather
 
-        // ---- each wave walks a contiguous piece of the sorted list, run by run ---------------
-        const int seg_lo = (int)(((int64_t)staged * wave) / nw), seg_hi = (int)(((int64_t)staged * (wave + 1)) / nw);
-        if (seg_lo < seg_hi) {
-            auto issue = [&](double2(&k)[NSTEP], int key) {
-                key = min(max(key, 0), nkeys - 1);  // never form an address outside the kernel table
-                const double2 *kp = gcf + (size_t)(first_slice + key) * S2;
+    // ---- each wave walks a contiguous piece of the sorted list ------------------------------------
+    // The piece is taken in blocks of 64 records: two coalesced loads bring a block into registers, one
+    // record per lane; runs of equal slice are found with a ballot and every per-record quantity is
+    // broadcast with v_readlane, so the accumulate loop issues nothing but arithmetic and ds_add_f64.
+    const int seg_lo = (int)(((int64_t)staged * wave) / nw), seg_hi = (int)(((int64_t)staged * (wave + 1)) / nw);
+    const long long walk_t0 = (ABL & 16) ? clock64() : 0;
+    // The SIMD's instruction arbiter favours its oldest wave, so the work-group's first four waves (one per
+    // SIMD) would finish their pieces at half the time of the last four, which then run on a half-idle LDS
+    // pipe.  Priorities in the opposite order even this out.
+    if (g.dbg & 32) {
+        switch (wave >> 2) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
+    if (seg_lo < seg_hi) {
+        auto load_block = [&](int b0, uint2 &mo, double2 &v) {
+            const int idx = max(min(b0 + lane, seg_hi - 1), seg_lo);  // past the end: the piece's last record
+            mo = smo[idx];
+            if (!DEGRID) v = svals[idx];
+        };
+        auto issue = [&](double2(&k)[NSTEP], int key) {
+            key = min(max(key, 0), nkeys - 1);  // never form an address outside the kernel table
+            asm volatile("" : "+s"(key));       // (an empty run repeats a key: keep its loads loads, not copies)
+            const double2 *kp = gcf + (size_t)(first_slice + key) * S2;
+            if (ABL & 4) {
 #pragma unroll
-                for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lane];
-                k[NSTEP - 1] = kp[ttail];
+                for (int s = 0; s < NSTEP; ++s) k[s] = make_double2((double)key, (double)(lane + s));
+                return;
+            }
+#pragma unroll
+            for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lane];
+            k[NSTEP - 1] = kp[ttail];
+        };
+        uint2 moN;
+        double2 vN = make_double2(0.0, 0.0);
+        load_block(seg_lo, moN, vN);
+        for (int b0 = seg_lo; b0 < seg_hi; b0 += 64) {
+            const uint2 mo = moN;
+            const double2 vB = vN;
+            load_block(b0 + 64, moN, vN);  // the next block's records travel while this one is accumulated
+            const int bcnt = min(64, seg_hi - b0);
+            const uint32_t mykey = mo.x >> 16;
+            const uint32_t prevkey = (uint32_t)__shfl_up((int)mykey, 1, 64);
+            unsigned long long bits = __ballot(lane < bcnt && (lane == 0 || mykey != prevkey));  // run starts
+            int lastKey = 0;
+            // next run of the block: its slice, first lane and length (an empty run once the block is used up)
+            auto advance = [&](int &key, int &start, int &len) {
+                if (bits == 0) {
+                    key = lastKey;
+                    start = 0;
+                    len = 0;
+                    return;
+                }
+                start = (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                len = (bits ? (int)__builtin_ctzll(bits) : bcnt) - start;
+                key = lastKey = (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, start) >> 16);
             };
-            // run starting at q0 with key key0: its length (<= 63) and the key that follows it
-            auto scan_run = [&](int q0, int key0, int &len, int &nextkey) {
-                const int idx = min(q0 + lane, seg_hi - 1);
-                const int k = (int)(meta[idx] >> 16);
-                const bool diff = (k != key0) && (q0 + lane < seg_hi);
-                const unsigned long long b = __ballot(diff);
-                int first = b ? (int)__builtin_ctzll(b) : 63;
-                first = min(first, 63);
-                len = min(first, seg_hi - q0);
-                len = max(len, 0);
-                nextkey = __builtin_amdgcn_readfirstlane(__shfl(k, min(len, 63), 64));
-                len = __builtin_amdgcn_readfirstlane(len);
-            };
-            auto process = [&](const double2(&k)[NSTEP], int q0, int len) {
-                uint32_t m = meta[min(q0, seg_hi - 1)];
-                if (!DEGRID) {
-                    double2 v = vals[min(q0, seg_hi - 1)];
-                    // Consume the two reads here: otherwise their wait lands in the loop header, where it
-                    // merges with the back edge into lgkmcnt(0) and every trip would drain the previous
-                    // visibility's eight ds_add_f64 before starting (checked in the ISA).
-                    asm volatile("" ::"v"(m), "v"(v.x), "v"(v.y));
-                    for (int i = 0; i < len; ++i) {
-                        const int qn = min(q0 + i + 1, seg_hi - 1);
-                        const uint32_t mn = meta[qn];  // next record's LDS reads go out before this one's atomics
-                        const double2 vn = vals[qn];
-                        const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+            auto process = [&](const double2(&k)[NSTEP], int start, int len) {
+                for (int i = 0; i < len; ++i) {
+                    const int j = start + i;
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
+                    const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+                    if (!DEGRID) {
+                        const double vx = readlane_f64(vB.x, j), vy = readlane_f64(vB.y, j);
 #pragma unroll
                         for (int s = 0; s < NSTEP; ++s) {
-                            double re = v.x * k[s].x - v.y * k[s].y;
-                            double im = v.x * k[s].y + v.y * k[s].x;
+                            double re = vx * k[s].x - vy * k[s].y;
+                            double im = vx * k[s].y + vy * k[s].x;
                             if (s == NSTEP - 1 && TAIL != 64) {
                                 re = tail_ok ? re : 0.0;
                                 im = tail_ok ? im : 0.0;
                             }
                             const int a = lbase + loff[s];
+                            if (ABL & 1) {
+                                if (re == 1.2345e300 || im == 1.2345e300) lre[a] = re;  // keeps the arithmetic alive
+                                continue;
+                            }
                             __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        m = mn;
-                        v = vn;
-                    }
-                } else {
-                    const int32_t *origs = reinterpret_cast<const int32_t *>(vals);
-                    int32_t o = origs[min(q0, seg_hi - 1)];
-                    asm volatile("" ::"v"(m), "v"(o));  // same reason as above
-                    for (int i = 0; i < len; ++i) {
-                        const int qn = min(q0 + i + 1, seg_hi - 1);
-                        const uint32_t mn = meta[qn];
-                        const int32_t on = origs[qn];
-                        const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+                    } else {
+                        const int32_t o = __builtin_amdgcn_readlane((int)mo.y, j);
                         double sr = 0.0, si = 0.0;
 #pragma unroll
                         for (int s = 0; s < NSTEP; ++s) {
@@ -230,8 +293,6 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                         sr = wave_sum_lane63(sr);
                         si = wave_sum_lane63(si);
                         if (lane == 63) vis[o] = make_double2(sr, si);
-                        m = mn;
-                        o = on;
                     }
                 }
             };
@@ -241,44 +302,50 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             // after a full A+B+C trip and every set is "used" after it, so LLVM cannot sink a
             // prefetch past the exit test; runs of length 0 pad the tail.
             double2 kA[NSTEP], kB[NSTEP], kC[NSTEP];
-            int q = seg_lo, lenA, lenB, lenC, keyA, keyB, keyC;
-            keyA = __builtin_amdgcn_readfirstlane((int)(meta[q] >> 16));
+            int keyA, startA, lenA, keyB, startB, lenB, keyC, startC, lenC;
+            advance(keyA, startA, lenA);
             issue(kA, keyA);
-            scan_run(q, keyA, lenA, keyB);
+            advance(keyB, startB, lenB);
             issue(kB, keyB);
-            scan_run(q + lenA, keyB, lenB, keyC);
+            int done = 0;
             for (;;) {
+                advance(keyC, startC, lenC);
                 issue(kC, keyC);
                 asm volatile("" ::: "memory");  // compiler fence: the prefetch may not sink below this point
                 __builtin_amdgcn_sched_barrier(0);
-                process(kA, q, lenA);
+                process(kA, startA, lenA);
                 __builtin_amdgcn_sched_barrier(0);
-                q += lenA;
-                scan_run(q + lenB, keyC, lenC, keyA);
+                done += lenA;
 
+                advance(keyA, startA, lenA);
                 issue(kA, keyA);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                process(kB, q, lenB);
+                process(kB, startB, lenB);
                 __builtin_amdgcn_sched_barrier(0);
-                q += lenB;
-                scan_run(q + lenC, keyA, lenA, keyB);
+                done += lenB;
 
+                advance(keyB, startB, lenB);
                 issue(kB, keyB);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                process(kC, q, lenC);
+                process(kC, startC, lenC);
                 __builtin_amdgcn_sched_barrier(0);
-                q += lenC;
-                if (q >= seg_hi) break;
-                scan_run(q + lenA, keyB, lenB, keyC);
+                done += lenC;
+                if (done >= bcnt) break;
             }
-            process(kA, q, 0);  // keep the last prefetches "used" on the exit path
-            process(kB, q, 0);
+            // The last two prefetches stay "used" on the exit path (in a branch that is never taken: done
+            // equals bcnt here), so LLVM cannot sink them below the exit test, and nothing waits for them.
+            if (done > bcnt) asm volatile("" ::"v"(kA[0].x), "v"(kA[NSTEP - 1].y), "v"(kB[0].x), "v"(kB[NSTEP - 1].y));
         }
     }
-    __syncthreads();  // all waves done with the tile (and with this item's staging)
-    if (DEGRID) continue;
+    if (g.dbg & 32) __builtin_amdgcn_s_setprio(0);
+    GH_STAMP(4)  // wave 0's own accumulate walk
+    if ((ABL & 16) && lane == 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(scalars + 32) + 8 + wave, (unsigned long long)(clock64() - walk_t0));
+    __syncthreads();  // all waves done with the tile (and with this item's sorted list)
+    GH_STAMP(5)  // waiting for the slowest wave
+    if (DEGRID || (ABL & 2)) continue;
 
     // ---- flush the cells that exist in the grid
     // Consecutive lanes take (re, im) of consecutive cells, so one atomic instruction covers a
@@ -294,12 +361,18 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
         unsafeAtomicAdd(grid + 2 * (gy * g.Wd + gx) + comp, val);
     }
     __syncthreads();  // the tile is re-initialised by the next work item
+    GH_STAMP(6)  // flush
     }  // persistent loop
+    if ((ABL & 16) && tid == 0) {
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(scalars + 32);
+        for (int i = 0; i < 7; ++i) atomicAdd(&out[i], (unsigned long long)prof[i]);
+    }
+#undef GH_STAMP
 }
 
 // Can the sorted variant run this geometry?  Needs a compile-time support, the per-group slice
-// count to fit the 16-bit key, and room next to the tile for the histogram and a useful batch of
-// staged records.  On success returns the LDS bytes and the batch size.
+// count to fit the 16-bit key and the tile coordinates 8 bits each, and room next to the tile for the
+// histogram.  On success returns the LDS bytes and the largest work item (records) it takes.
 bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, int *batch, size_t *lds_bytes)
 {
     // square supports with a compile-time instantiation below
@@ -310,15 +383,13 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     if (keys >= 65536) return false;
     const size_t tile = (size_t)g.lrows * g.ldw * 16;
     const size_t hist = (size_t)((keys + 1 + 3) & ~3) * 4;
-    if (tile + hist + 512 * 20 + 512 > (size_t)ctx->max_lds) return false;
-    int c = (int)(((size_t)ctx->max_lds - 1024 - tile - hist) / 20);
+    if (tile + hist + 128 > (size_t)ctx->max_lds) return false;
     (void)block;
-    c &= ~63;
-    if (c > 8192) c = 8192;
-    if (c < 512) return false;
+    int c = ctx->opt.chunk ? (int)ctx->opt.chunk : 8192;
+    c = c < 64 ? 64 : c > 16384 ? 16384 : c;
     *nkeys = (int)keys;
     *batch = c;
-    *lds_bytes = tile + hist + (size_t)c * 20 + 16;  // + the work-queue slot
+    *lds_bytes = tile + hist + 128;  // + per-wave scan totals and the work-queue slot
     return true;
 }
 
@@ -327,6 +398,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
 {
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
+    if (g.chunk > batch) return fail(ctx, GRIDHIP_EINVAL, "sorted kernel: chunk %d exceeds its work-item capacity %d", g.chunk, batch);
     // persistent work-groups: as many as can be resident (LDS-limited), pulling items from per-group queues
     int per_cu = (int)((size_t)ctx->max_lds / lds_bytes);
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
@@ -336,13 +408,18 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     const int most = work_blocks(g, n);
     if (nblk > most) nblk = most > g.ngroups ? (most / g.ngroups) * g.ngroups : g.ngroups;
     const dim3 gr(nblk), bl(block);
+    // the sorted list of every resident work item: 16 B value + 8 B (meta, orig) per record
+    GH_CHECK(ws_reserve(ctx, ctx->sorted, (size_t)nblk * batch * 24));
+    double2 *svals = (double2 *)ctx->sorted.ptr;
+    uint2 *smo = (uint2 *)(svals + (size_t)nblk * batch);
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 4, 0, 8 * sizeof(int32_t), ctx->stream));
+    if (g.dbg & 16) GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 32, 0, 64 * sizeof(int32_t), ctx->stream));
 #define GH_LAUNCH(S_, D_)                                                                                        \
     do {                                                                                                         \
         GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_>));                                               \
         hipLaunchKernelGGL((tile_grid_sorted_kernel<S_, D_>), gr, bl, lds_bytes, ctx->stream, g, recs,           \
                            t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
-                           t.scalars);                                                                           \
+                           t.scalars, svals, smo);                                                               \
     } while (0)
 #define GH_CASE(S_)             \
     case S_:                    \
@@ -351,6 +428,17 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
         else                    \
             GH_LAUNCH(S_, false); \
         break;
+#define GH_ABL(A_)                                                                                               \
+    if (g.gh == 15 && !degrid && g.dbg == A_) {                                                                  \
+        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<15, false, A_>));                                        \
+        hipLaunchKernelGGL((tile_grid_sorted_kernel<15, false, A_>), gr, bl, lds_bytes, ctx->stream, g, recs,    \
+                           t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
+                           t.scalars, svals, smo);                                                               \
+        GH_CHECK_HIP(ctx, hipGetLastError());                                                                    \
+        return GRIDHIP_OK;                                                                                       \
+    }
+    GH_ABL(1) GH_ABL(2) GH_ABL(3) GH_ABL(4) GH_ABL(5) GH_ABL(7) GH_ABL(8) GH_ABL(15) GH_ABL(16) GH_ABL(48)
+#undef GH_ABL
     switch (g.gh) {
         GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)
         GH_CASE(14) GH_CASE(15) GH_CASE(16)
