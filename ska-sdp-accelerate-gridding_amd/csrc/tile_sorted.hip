@@ -31,6 +31,18 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // ABL (tuning runs only, option "dbg"): bit 0 = no LDS atomics in the accumulate loop, bit 1 = no flush,
 // bit 2 = no tap loads, bit 3 = no visibility gather, bit 4 = per-phase cycle stamps.  Results are wrong
 // with any of bits 0..3 set.
+//
+// Roles.  The work-group's last wave is the SORTER: it pulls the next work item from the queues and
+// counting-sorts its records into the other half of the scratch while the remaining waves (WALKERS)
+// accumulate the current item; the accumulate loop is bound by the LDS atomic unit, which the sorter
+// barely touches, so the sort's latency chains (record load -> LDS histogram slot -> value gather ->
+// store) disappear behind it.  A work-group of one wave does both, one after the other.
+constexpr int SORTED_IM_OFF = 65528;  // largest multiple of 8 that a DS instruction's offset field holds
+
+struct SortedItem {
+    int32_t valid, tile, grp, staged;
+};
+
 template <int S, bool DEGRID, int ABL = 0>
 __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
@@ -49,165 +61,167 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int plane = g.lrows * g.ldw;
-    // LDS: tile (re plane, im plane) | histogram | per-wave scan totals, work-queue slot
-    double *lre = lds, *lim = lds + plane;
-    int32_t *hist = reinterpret_cast<int32_t *>(lds + 2 * plane);
+    // LDS: re plane | (gap) | im plane at the fixed byte offset SORTED_IM_OFF | histogram | two item descriptors.
+    // The fixed distance lets one address register serve both atomics of a tap: the im one carries the
+    // distance in its offset field (16 bits, hence the value), which takes a VALU add per tap step out of
+    // the accumulate loop.
+    double *lre = lds, *lim = lds + SORTED_IM_OFF / 8;
+    int32_t *hist = reinterpret_cast<int32_t *>(lim + plane);
     const int hist_words = (nkeys + 1 + 3) & ~3;
-    int32_t *wsum = hist + hist_words;  // [16]
-    int32_t *s_item = wsum + 16;
-    // this work-group's slice of the sorted-list scratch
-    double2 *svals = sorted_vals + (size_t)blockIdx.x * batch;
-    uint2 *smo = sorted_mo + (size_t)blockIdx.x * batch;
+    SortedItem *desc = reinterpret_cast<SortedItem *>(hist + hist_words);  // [2]
+    // this work-group's two halves of the sorted-list scratch
+    double2 *svals_wg = sorted_vals + (size_t)blockIdx.x * 2 * batch;
+    uint2 *smo_wg = sorted_mo + (size_t)blockIdx.x * 2 * batch;
 
-    // Persistent work-groups: the launch has one work-group per CU slot; each pulls work items of
-    // "its" w-group (blockIdx % ngroups: the group whose kernel planes this XCD's L2 holds) from a
-    // queue counter, then helps the other groups when its own queue is empty.  Every wave leaves
-    // the loop once all queues are exhausted; there is no waiting on other work-groups.
-    int32_t *queue = scalars + 4;
-    long long prof[7] = {0, 0, 0, 0, 0, 0, 0}, pt = 0;  // ABL & 16: cycles per phase, thread 0
+    const bool solo = nw == 1;
+    const bool is_sorter = wave == nw - 1;
+    const bool is_walker = solo || !is_sorter;
+    const int nwalk = solo ? 1 : nw - 1;
+    const int ncell = g.lrows * g.lcols;
+
+    long long prof[7] = {0, 0, 0, 0, 0, 0, 0}, pt = 0;  // ABL & 16: cycles per phase, first lane of the stamping wave
 #define GH_STAMP(i_)                        \
-    if ((ABL & 16) && tid == 0) {           \
+    if ((ABL & 16) && lane == 0) {          \
         const long long now_ = clock64();   \
         prof[i_] += now_ - pt;              \
         pt = now_;                          \
     }
-    if ((ABL & 16) && tid == 0) pt = clock64();
-    for (int turn = 0; turn < g.ngroups;) {
-    const int grp = (blockIdx.x + turn) % g.ngroups;
-    if (tid == 0) *s_item = atomicAdd(&queue[grp], 1);
-    __syncthreads();
-    const int item = *s_item;
-    __syncthreads();
-    WorkItem w;
-    if (!find_work_at(g, bin_start, work_start, grp, item, &w)) {
-        ++turn;  // this group's queue is exhausted (uniform across the work-group)
-        continue;
-    }
-    const int first_plane = (grp * g.W + g.ngroups - 1) / g.ngroups;  // smallest wb with wb*ng/W == grp
-    const int first_slice = first_plane * g.Q * g.Q;
+    if ((ABL & 16) && lane == 0) pt = clock64();
 
-    const int tx = w.tile % g.ntx, ty = w.tile / g.ntx;
-    const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
-    const int ncell = g.lrows * g.lcols;
-    if (!DEGRID) {
-        double2 *z = reinterpret_cast<double2 *>(lds);
-        for (int i = tid; i < plane; i += nthr) z[i] = make_double2(0.0, 0.0);
-    } else {
-        const double2 *gsrc = reinterpret_cast<const double2 *>(grid);
-        for (int c = tid; c < ncell; c += nthr) {
-            const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
-            const int64_t gx = ox + c_, gy = oy + r_;
-            double2 v = make_double2(0.0, 0.0);
-            if (gx >= 0 && gy >= 0 && gx < g.Wd && gy < g.H) v = gsrc[gy * g.Wd + gx];
-            lre[r_ * g.ldw + c_] = v.x;
-            lim[r_ * g.ldw + c_] = v.y;
+    // ---- the sorter's job: fetch a work item and leave it sorted in scratch half `slot` -----------------
+    // Persistent work-groups: the launch has one work-group per CU slot; each pulls work items of
+    // "its" w-group (blockIdx % ngroups: the group whose kernel planes this XCD's L2 holds) from a
+    // queue counter, then helps the other groups when its own queue is empty.
+    int32_t *queue = scalars + 4;
+    int turn = 0;  // sorter state: how many queues this work-group has seen empty
+    auto prepare = [&](int slot) {
+        WorkItem w;
+        int grp = 0;
+        bool have = false;
+        while (turn < g.ngroups) {
+            grp = (blockIdx.x + turn) % g.ngroups;
+            int item = 0;
+            if (lane == 0) item = atomicAdd(&queue[grp], 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (find_work_at(g, bin_start, work_start, grp, item, &w)) {
+                have = true;
+                break;
+            }
+            ++turn;  // this group's queue is exhausted
         }
-    }
+        if (!have) {
+            if (lane == 0) desc[slot].valid = 0;
+            return;
+        }
+        GH_STAMP(0)  // work fetch
+        const int first_plane = (grp * g.W + g.ngroups - 1) / g.ngroups;  // smallest wb with wb*ng/W == grp
+        const int first_slice = first_plane * g.Q * g.Q;
+        double2 *svals = svals_wg + (size_t)slot * batch;
+        uint2 *smo = smo_wg + (size_t)slot * batch;
+        const int b_lo = w.v_lo;
+        const int cnt = min(batch, w.v_hi - b_lo);  // a work item never holds more than `batch` records
+        // counting sort by kernel slice, one wave: LDS operations of a wave execute in program order; the
+        // fences keep the compiler from reordering them across the phases
+        for (int i = lane; i <= nkeys; i += 64) hist[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int r0 = lane; r0 < cnt; r0 += 8 * 64) {
+            int key[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) key[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1)).kslice - first_slice;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + q * 64 < cnt && (unsigned)key[q] < (unsigned)nkeys) atomicAdd(&hist[key[q]], 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GH_STAMP(1)  // histogram
+        {   // exclusive scan of hist[0..nkeys): each lane owns a contiguous strip
+            const int per = (nkeys + 63) / 64;
+            const int lo = min(lane * per, nkeys), hi = min(lo + per, nkeys);
+            int sum = 0;
+            for (int i = lo; i < hi; ++i) sum += hist[i];
+            int incl = sum;  // inclusive scan across the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            int base = incl - sum;
+            for (int i = lo; i < hi; ++i) {
+                const int c = hist[i];
+                hist[i] = base;
+                base += c;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GH_STAMP(2)  // scan
+        int bad = 0;
+        // eight records per lane and trip: their record loads, then their value gathers, are all in flight
+        // together (the gather is a dependent, HBM-random access)
+        for (int r0 = lane; r0 < cnt; r0 += 8 * 64) {
+            VisRec rec[8];
+            double2 val[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rec[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1));
+            if (!DEGRID) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) val[q] = (ABL & 8) ? make_double2(1.0, (double)q) : vis[rec[q].orig];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (r0 + q * 64 >= cnt) break;
+                const int key = rec[q].kslice - first_slice;
+                if ((unsigned)key >= (unsigned)nkeys) {  // cannot happen unless binning and kernel disagree
+                    ++bad;
+                    continue;
+                }
+                const int pos = atomicAdd(&hist[key], 1);
+                if ((unsigned)pos < (unsigned)batch) {
+                    smo[pos] = make_uint2(((uint32_t)key << 16) | (uint32_t)((rec[q].lxy >> 16) << 8) |
+                                              (uint32_t)(rec[q].lxy & 0xff),
+                                          (uint32_t)rec[q].orig);
+                    if (!DEGRID) svals[pos] = val[q];
+                } else
+                    ++bad;
+            }
+        }
+        if (bad) atomicAdd(&scalars[2], bad);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // records that were rejected leave holes at the end of the sorted list: hist[nkeys-1] is now
+        // the number actually staged
+        if (lane == 0) {
+            SortedItem d;
+            d.valid = 1;
+            d.tile = w.tile;
+            d.grp = grp;
+            d.staged = hist[nkeys - 1];
+            desc[slot] = d;
+        }
+        GH_STAMP(3)  // scatter + value gather
+    };
 
     int loff[NSTEP];
     const bool tail_ok = lane < TAIL || TAIL == 64;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
         int t = s * 64 + lane;
-        if (s == NSTEP - 1 && !tail_ok) t = lane - 32;  // adds 0.0 on an idle bank pair (see tile_grid.hip)
+        if (s == NSTEP - 1 && !tail_ok) t = 0;  // idle lanes of the last step (switched off there)
         loff[s] = (t / S) * g.ldw + (t % S);
     }
     const int ttail = tail_ok ? (NSTEP - 1) * 64 + lane : 0;
 
-    // a work item never holds more than `batch` records (the host sets chunk <= batch)
-    const int b_lo = w.v_lo;
-    const int cnt = min(batch, w.v_hi - b_lo);
-
-    // ---- counting sort of the item's records by kernel slice ---------------------------------
-    GH_STAMP(0)  // work fetch, tile init
-    for (int i = tid; i <= nkeys; i += nthr) hist[i] = 0;
-    __syncthreads();
-    for (int r = tid; r < cnt; r += nthr) {
-        const VisRec rec = load_rec(recs, b_lo + r);
-        const int key = rec.kslice - first_slice;
-        if ((unsigned)key < (unsigned)nkeys) atomicAdd(&hist[key], 1);
-    }
-    __syncthreads();
-    GH_STAMP(1)  // histogram
-    {   // exclusive scan of hist[0..nkeys): each thread owns a contiguous strip
-        const int per = (nkeys + nthr - 1) / nthr;
-        const int lo = min(tid * per, nkeys), hi = min(lo + per, nkeys);
-        int s = 0;
-        for (int i = lo; i < hi; ++i) s += hist[i];
-        int incl = s;  // inclusive scan across the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int base = incl - s;
-        for (int ww = 0; ww < wave; ++ww) base += wsum[ww];
-        for (int i = lo; i < hi; ++i) {
-            const int c = hist[i];
-            hist[i] = base;
-            base += c;
-        }
-    }
-    __syncthreads();
-    GH_STAMP(2)  // scan
-    int bad = 0;
-    // four records per thread and trip: their record loads, then their value gathers, are all in flight
-    // together (the gather is a dependent, HBM-random access; taken one record at a time its latency
-    // is the whole phase)
-    for (int r0 = tid; r0 < cnt; r0 += 4 * nthr) {
-        VisRec rec[4];
-        double2 val[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rec[q] = load_rec(recs, b_lo + min(r0 + q * nthr, cnt - 1));
-        if (!DEGRID) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) val[q] = (ABL & 8) ? make_double2(1.0, (double)q) : vis[rec[q].orig];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (r0 + q * nthr >= cnt) break;
-            const int key = rec[q].kslice - first_slice;
-            if ((unsigned)key >= (unsigned)nkeys) {  // cannot happen unless binning and kernel disagree
-                ++bad;
-                continue;
-            }
-            const int pos = atomicAdd(&hist[key], 1);
-            if ((unsigned)pos < (unsigned)batch) {
-                smo[pos] = make_uint2(((uint32_t)key << 16) | (uint32_t)((rec[q].lxy >> 16) << 8) |
-                                          (uint32_t)(rec[q].lxy & 0xff),
-                                      (uint32_t)rec[q].orig);
-                if (!DEGRID) svals[pos] = val[q];
-            } else
-                ++bad;
-        }
-    }
-    if (bad) atomicAdd(&scalars[2], bad);
-    __syncthreads();  // (also makes the scratch writes visible to the work-group's other waves)
-    // records that were rejected leave holes at the end of the sorted list: hist[nkeys-1] is now
-    // the number actually staged
-    const int staged = hist[nkeys - 1];
-    GH_STAMP(3)  // scatter + value gather
-
-    // ---- each wave walks a contiguous piece of the sorted list ------------------------------------
+    // ---- a walker's job: its piece of the sorted list of scratch half `slot` ------------------------------
     // The piece is taken in blocks of 64 records: two coalesced loads bring a block into registers, one
     // record per lane; runs of equal slice are found with a ballot and every per-record quantity is
     // broadcast with v_readlane, so the accumulate loop issues nothing but arithmetic and ds_add_f64.
-    const int seg_lo = (int)(((int64_t)staged * wave) / nw), seg_hi = (int)(((int64_t)staged * (wave + 1)) / nw);
-    const long long walk_t0 = (ABL & 16) ? clock64() : 0;
-    // The SIMD's instruction arbiter favours its oldest wave, so the work-group's first four waves (one per
-    // SIMD) would finish their pieces at half the time of the last four, which then run on a half-idle LDS
-    // pipe.  Priorities in the opposite order even this out.
-    if (g.dbg & 32) {
-        switch (wave >> 2) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-        }
-    }
-    if (seg_lo < seg_hi) {
+    auto walk = [&](int slot, int staged, int first_slice) {
+        const double2 *svals = svals_wg + (size_t)slot * batch;
+        const uint2 *smo = smo_wg + (size_t)slot * batch;
+        const int seg_lo = (int)(((int64_t)staged * wave) / nwalk), seg_hi = (int)(((int64_t)staged * (wave + 1)) / nwalk);
+        if (seg_lo >= seg_hi) return;
         auto load_block = [&](int b0, uint2 &mo, double2 &v) {
             const int idx = max(min(b0 + lane, seg_hi - 1), seg_lo);  // past the end: the piece's last record
             mo = smo[idx];
@@ -260,35 +274,32 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                         const double vx = readlane_f64(vB.x, j), vy = readlane_f64(vB.y, j);
 #pragma unroll
                         for (int s = 0; s < NSTEP; ++s) {
-                            double re = vx * k[s].x - vy * k[s].y;
-                            double im = vx * k[s].y + vy * k[s].x;
-                            if (s == NSTEP - 1 && TAIL != 64) {
-                                re = tail_ok ? re : 0.0;
-                                im = tail_ok ? im : 0.0;
-                            }
-                            const int a = lbase + loff[s];
+                            const double re = vx * k[s].x - vy * k[s].y;
+                            const double im = vx * k[s].y + vy * k[s].x;
+                            double *cell = lre + (lbase + loff[s]);
                             if (ABL & 1) {
-                                if (re == 1.2345e300 || im == 1.2345e300) lre[a] = re;  // keeps the arithmetic alive
+                                if (re == 1.2345e300 || im == 1.2345e300) *cell = re;  // keeps the arithmetic alive
                                 continue;
                             }
-                            __hip_atomic_fetch_add(&lre[a], re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(&lim[a], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            // the last step's idle lanes are switched off (EXEC): an LDS atomic costs 8 cycles with
+                            // all four 16-lane groups active, 7 with three (tools/micro/lds_atomic.hip)
+                            if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
+                                __hip_atomic_fetch_add(cell, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, im, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                     } else {
                         const int32_t o = __builtin_amdgcn_readlane((int)mo.y, j);
                         double sr = 0.0, si = 0.0;
 #pragma unroll
                         for (int s = 0; s < NSTEP; ++s) {
-                            const int a = lbase + loff[s];
-                            const double gr = lre[a], gi = lim[a];
-                            double pr = k[s].x * gr - k[s].y * gi;
-                            double pi = k[s].x * gi + k[s].y * gr;
-                            if (s == NSTEP - 1 && TAIL != 64) {
-                                pr = tail_ok ? pr : 0.0;
-                                pi = tail_ok ? pi : 0.0;
+                            const double *cell = lre + (lbase + loff[s]);
+                            if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
+                                const double gr = cell[0], gi = cell[SORTED_IM_OFF / 8];
+                                sr += k[s].x * gr - k[s].y * gi;
+                                si += k[s].x * gi + k[s].y * gr;
                             }
-                            sr += pr;
-                            si += pi;
                         }
                         sr = wave_sum_lane63(sr);
                         si = wave_sum_lane63(si);
@@ -338,34 +349,72 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             // equals bcnt here), so LLVM cannot sink them below the exit test, and nothing waits for them.
             if (done > bcnt) asm volatile("" ::"v"(kA[0].x), "v"(kA[NSTEP - 1].y), "v"(kB[0].x), "v"(kB[NSTEP - 1].y));
         }
-    }
-    if (g.dbg & 32) __builtin_amdgcn_s_setprio(0);
-    GH_STAMP(4)  // wave 0's own accumulate walk
-    if ((ABL & 16) && lane == 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(scalars + 32) + 8 + wave, (unsigned long long)(clock64() - walk_t0));
-    __syncthreads();  // all waves done with the tile (and with this item's sorted list)
-    GH_STAMP(5)  // waiting for the slowest wave
-    if (DEGRID || (ABL & 2)) continue;
+    };
 
-    // ---- flush the cells that exist in the grid
-    // Consecutive lanes take (re, im) of consecutive cells, so one atomic instruction covers a
-    // contiguous 512-byte run of the interleaved grid row (memory-side fp64 atomics run at full rate
-    // on contiguous runs and at half of it on the stride-16 pattern of one component at a time).
-    for (int e = tid; e < 2 * ncell; e += nthr) {
-        const int c = e >> 1, comp = e & 1;
-        const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
-        const int64_t gx = ox + c_, gy = oy + r_;
-        if (gx < 0 || gy < 0 || gx >= g.Wd || gy >= g.H) continue;
-        const double val = comp ? lim[r_ * g.ldw + c_] : lre[r_ * g.ldw + c_];
-        if (val == 0.0) continue;
-        unsafeAtomicAdd(grid + 2 * (gy * g.Wd + gx) + comp, val);
+    // ---- pipeline: item i is accumulated while item i+1 is fetched and sorted ---------------------------
+    if (is_sorter) prepare(0);
+    if (!DEGRID) {
+        for (int i = tid; i < plane; i += nthr) {
+            lre[i] = 0.0;
+            lim[i] = 0.0;
+        }
     }
-    __syncthreads();  // the tile is re-initialised by the next work item
-    GH_STAMP(6)  // flush
-    }  // persistent loop
-    if ((ABL & 16) && tid == 0) {
+    __syncthreads();
+    for (int cur = 0;; cur ^= 1) {
+        const SortedItem d = desc[cur];
+        if (!d.valid) break;  // uniform across the work-group
+        const int first_plane = (d.grp * g.W + g.ngroups - 1) / g.ngroups;
+        const int first_slice = first_plane * g.Q * g.Q;
+        const int tx = d.tile % g.ntx, ty = d.tile / g.ntx;
+        const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
+        if (DEGRID) {
+            const double2 *gsrc = reinterpret_cast<const double2 *>(grid);
+            for (int c = tid; c < ncell; c += nthr) {
+                const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
+                const int64_t gx = ox + c_, gy = oy + r_;
+                double2 v = make_double2(0.0, 0.0);
+                if (gx >= 0 && gy >= 0 && gx < g.Wd && gy < g.H) v = gsrc[gy * g.Wd + gx];
+                lre[r_ * g.ldw + c_] = v.x;
+                lim[r_ * g.ldw + c_] = v.y;
+            }
+            __syncthreads();
+        }
+        const long long walk_t0 = (ABL & 16) ? clock64() : 0;
+        if (is_sorter && !solo) prepare(cur ^ 1);
+        if (is_walker) {
+            if ((ABL & 16) && wave == 0 && lane == 0) pt = clock64();
+            walk(cur, d.staged, first_slice);
+            if ((ABL & 16) && wave == 0) GH_STAMP(4)  // wave 0's own accumulate walk
+        }
+        if (solo) prepare(cur ^ 1);
+        if ((ABL & 16) && lane == 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(scalars + 32) + 8 + wave, (unsigned long long)(clock64() - walk_t0));
+        __syncthreads();  // the tile is complete, the next item's sorted list and descriptor are in place
+        if ((ABL & 16) && wave == 0) GH_STAMP(5)  // waiting for the slowest wave
+        if (DEGRID) continue;
+
+        // ---- flush the cells that exist in the grid, and clear the tile for the next item
+        // Consecutive lanes take (re, im) of consecutive cells, so one atomic instruction covers a
+        // contiguous 512-byte run of the interleaved grid row (memory-side fp64 atomics run at full rate
+        // on contiguous runs and at half of it on the stride-16 pattern of one component at a time).
+        for (int e = tid; e < 2 * ncell; e += nthr) {
+            const int c = e >> 1, comp = e & 1;
+            const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
+            const int64_t gx = ox + c_, gy = oy + r_;
+            double *cell = (comp ? lim : lre) + r_ * g.ldw + c_;
+            const double val = *cell;
+            if (val == 0.0) continue;
+            *cell = 0.0;
+            if ((ABL & 2) || gx < 0 || gy < 0 || gx >= g.Wd || gy >= g.H) continue;
+            unsafeAtomicAdd(grid + 2 * (gy * g.Wd + gx) + comp, val);
+        }
+        __syncthreads();
+        if ((ABL & 16) && wave == 0) GH_STAMP(6)  // flush
+    }
+    if ((ABL & 16) && lane == 0 && (wave == 0 || (is_sorter && !solo))) {
         unsigned long long *out = reinterpret_cast<unsigned long long *>(scalars + 32);
-        for (int i = 0; i < 7; ++i) atomicAdd(&out[i], (unsigned long long)prof[i]);
+        for (int i = 0; i < 7; ++i)
+            if (prof[i]) atomicAdd(&out[i], (unsigned long long)prof[i]);
     }
 #undef GH_STAMP
 }
@@ -381,7 +430,9 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     const int planes = (g.W + g.ngroups - 1) / g.ngroups + 1;  // groups differ by at most one plane
     const int64_t keys = (int64_t)planes * g.Q * g.Q;
     if (keys >= 65536) return false;
-    const size_t tile = (size_t)g.lrows * g.ldw * 16;
+    const size_t plane = (size_t)g.lrows * g.ldw * 8;
+    if (plane > (size_t)SORTED_IM_OFF) return false;
+    const size_t tile = (size_t)SORTED_IM_OFF + plane;  // re plane, gap, im plane
     const size_t hist = (size_t)((keys + 1 + 3) & ~3) * 4;
     if (tile + hist + 128 > (size_t)ctx->max_lds) return false;
     (void)block;
@@ -389,7 +440,7 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     c = c < 64 ? 64 : c > 16384 ? 16384 : c;
     *nkeys = (int)keys;
     *batch = c;
-    *lds_bytes = tile + hist + 128;  // + per-wave scan totals and the work-queue slot
+    *lds_bytes = tile + hist + 128;  // + the item descriptors
     return true;
 }
 
@@ -408,10 +459,10 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     const int most = work_blocks(g, n);
     if (nblk > most) nblk = most > g.ngroups ? (most / g.ngroups) * g.ngroups : g.ngroups;
     const dim3 gr(nblk), bl(block);
-    // the sorted list of every resident work item: 16 B value + 8 B (meta, orig) per record
-    GH_CHECK(ws_reserve(ctx, ctx->sorted, (size_t)nblk * batch * 24));
+    // two sorted lists (current item, next item) per resident work-group: 16 B value + 8 B (meta, orig) per record
+    GH_CHECK(ws_reserve(ctx, ctx->sorted, (size_t)nblk * 2 * batch * 24));
     double2 *svals = (double2 *)ctx->sorted.ptr;
-    uint2 *smo = (uint2 *)(svals + (size_t)nblk * batch);
+    uint2 *smo = (uint2 *)(svals + (size_t)nblk * 2 * batch);
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 4, 0, 8 * sizeof(int32_t), ctx->stream));
     if (g.dbg & 16) GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 32, 0, 64 * sizeof(int32_t), ctx->stream));
 #define GH_LAUNCH(S_, D_)                                                                                        \
