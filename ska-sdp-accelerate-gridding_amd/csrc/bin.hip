@@ -7,6 +7,16 @@
 //   bin_offsets : per-work-group histograms -> each work-group's first slot in every bin
 //   bin_scatter : second sweep writes each visibility's VisRec into its work-group's slot range
 //
+// Large streams take the scatter in two levels instead (option "prepass": 0 = auto, 1 = one level,
+// 2 = two levels).  A record written straight to its bin is a lone 16-byte store into one of ~10^5
+// open regions, i.e. one partial-line HBM write per visibility, which is what bounds the one-level
+// sweep (2.6 ms for 10^8 records against 0.45 ms for the counting sweep over the same input).
+//   coarse_scatter : chunks of 4096 visibilities are counting-sorted by COARSE bin (2^k consecutive
+//                    bins) in LDS and written as runs into a temporary array laid out like the final
+//                    one at coarse granularity
+//   fine_scatter   : segments of the temporary array (a handful of coarse bins each, so few open
+//                    lines per work-group: the L2 merges them) are distributed to their bins
+//
 // Coordinates follow frac_coords / convgrid2 of src/Gridding.hs:126-151,212-218: the footprint
 // origin is (x - gw/2, y - gh/2); a visibility none of whose taps can land inside the grid is
 // dropped here (fixoutofbounds would drop every one of its taps, :883-891).
@@ -95,10 +105,10 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
         __syncthreads();
         // keep this block's histogram: bin_offsets_kernel turns it into the block's first slot per
         // bin, so the scatter pass needs neither a recount nor slot-reservation atomics
-        int32_t *mine = block_hist + (size_t)blockIdx.x * g.nbins + bin_lo;
+        int32_t *mine = block_hist ? block_hist + (size_t)blockIdx.x * g.nbins + bin_lo : nullptr;
         for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
             int c = hist[i];
-            mine[i] = c;
+            if (mine) mine[i] = c;  // (the two-level scatter reserves its slots differently)
             if (c) atomicAdd(&bin_count[bin_lo + i], c);
         }
     }
@@ -225,6 +235,161 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
     }
 }
 
+// ---- two-level scatter ----------------------------------------------------------------------
+constexpr int COARSE_CHUNK = 4096;  // visibilities per LDS sort (64 KB of records: two work-groups per CU)
+
+// Level 1.  tmp is laid out like the final record array at coarse granularity: coarse bin c owns
+// [bin_start[c << shift], bin_start[min((c + 1) << shift, nbins)]).  Each chunk reserves, per coarse bin, a
+// contiguous range there (one global atomic per chunk and non-empty coarse bin) and writes its records as
+// runs; the record's spare word carries its bin for level 2.
+__global__ void __launch_bounds__(1024) coarse_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
+                                                              const double *__restrict__ v, int64_t stride,
+                                                              const int64_t *__restrict__ wbin,
+                                                              const int32_t *__restrict__ bin_start,
+                                                              int32_t *__restrict__ ccur, int shift, int ncoarse,
+                                                              VisRec *__restrict__ tmp)
+{
+    extern __shared__ int32_t smem[];
+    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [COARSE_CHUNK]
+    int32_t *hist = smem + COARSE_CHUNK * 4;            // [ncoarse]: count, then the coarse bin's first slot in `sorted`
+    int32_t *gbase = hist + ncoarse;                    // [ncoarse]: tmp position of sorted[0] if it were in this bin
+    int32_t *wtot = gbase + ncoarse;                    // [16] per-wave totals of the scan, [16] = chunk total
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = COARSE_CHUNK / 1024;
+    int64_t lo, hi;
+    block_range(n, &lo, &hi);
+    for (int64_t c0 = lo; c0 < hi; c0 += COARSE_CHUNK) {
+        for (int i = tid; i < ncoarse; i += 1024) hist[i] = 0;
+        __syncthreads();
+        BinOut b[PER];
+        int rank[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t k = c0 + q * 1024 + tid;
+            b[q].bin = -1;
+            if (k < hi) b[q] = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            rank[q] = b[q].bin >= 0 ? atomicAdd(&hist[b[q].bin >> shift], 1) : 0;
+        __syncthreads();
+        // exclusive scan of the counts (ncoarse <= 1024: one entry per thread) and the global reservations
+        {
+            const int c = tid < ncoarse ? hist[tid] : 0;
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            int base = incl - c;
+            for (int w = 0; w < wave; ++w) base += wtot[w];
+            if (tid < ncoarse) {
+                hist[tid] = base;
+                if (c) {
+                    const int first = tid << shift;
+                    gbase[tid] = bin_start[first] + atomicAdd(&ccur[tid], c) - base;
+                }
+            }
+            if (tid == 1023) wtot[16] = base + c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (b[q].bin < 0) continue;
+            VisRec r;
+            r.lxy = b[q].lxy;
+            r.kslice = b[q].kslice;
+            r.orig = (int32_t)(c0 + q * 1024 + tid);
+            r.pad = b[q].bin;
+            sorted[hist[b[q].bin >> shift] + rank[q]] = r;
+        }
+        __syncthreads();
+        const int total = wtot[16];
+        for (int i = tid; i < total; i += 1024) {
+            const int4 r = *reinterpret_cast<const int4 *>(sorted + i);
+            *reinterpret_cast<int4 *>(tmp + gbase[r.w >> shift] + i) = r;  // neighbouring lanes: neighbouring slots
+        }
+        __syncthreads();
+    }
+}
+
+// Level 2.  Work-group w takes the w-th equal share of tmp in chunks of COARSE_CHUNK records.  tmp is ordered by
+// coarse bin, so a chunk's bins lie between the coarse bins of its first and last record: normally one or two
+// coarse bins, i.e. at most a few hundred bins.  The chunk is counting-sorted by bin in LDS exactly as level 1 sorts
+// by coarse bin, each bin's range is reserved with one global atomic, and the records leave as runs.  A chunk that
+// spans more than 1024 bins (very sparse regions) falls back to one global atomic per record.
+__global__ void __launch_bounds__(1024) fine_scatter_kernel(Geom g, const int32_t *__restrict__ bin_start,
+                                                            int32_t *__restrict__ cursor, int shift,
+                                                            const VisRec *__restrict__ tmp, VisRec *__restrict__ recs)
+{
+    extern __shared__ int32_t smem[];
+    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [COARSE_CHUNK]
+    int32_t *hist = smem + COARSE_CHUNK * 4;            // [1024]
+    int32_t *gbase = hist + 1024;                       // [1024]
+    int32_t *wtot = gbase + 1024;                       // [17]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = COARSE_CHUNK / 1024;
+    const int64_t ntot = bin_start[g.nbins];
+    int64_t per = (ntot + gridDim.x - 1) / gridDim.x;
+    per = (per + COARSE_CHUNK - 1) / COARSE_CHUNK * COARSE_CHUNK;
+    const int64_t lo = min((int64_t)blockIdx.x * per, ntot), hi = min(lo + per, ntot);
+    for (int64_t c0 = lo; c0 < hi; c0 += COARSE_CHUNK) {
+        const int64_t c1 = min(c0 + COARSE_CHUNK, hi);
+        const int cb_first = tmp[c0].pad >> shift, cb_last = tmp[c1 - 1].pad >> shift;
+        const int b0 = cb_first << shift, span = (cb_last - cb_first + 1) << shift;
+        if (span > 1024) {  // rare: one global atomic per record
+            for (int64_t i = c0 + tid; i < c1; i += 1024) {
+                const int4 r = *reinterpret_cast<const int4 *>(tmp + i);
+                const int slot = bin_start[r.w] + atomicAdd(&cursor[r.w], 1);
+                *reinterpret_cast<int4 *>(recs + slot) = r;
+            }
+            continue;
+        }
+        hist[tid] = 0;
+        __syncthreads();
+        int4 r[PER];
+        int rank[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t i = c0 + q * 1024 + tid;
+            r[q] = make_int4(0, 0, 0, -1);
+            if (i < c1) r[q] = *reinterpret_cast<const int4 *>(tmp + i);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) rank[q] = r[q].w >= 0 ? atomicAdd(&hist[r[q].w - b0], 1) : 0;
+        __syncthreads();
+        {
+            const int c = hist[tid];
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            int base = incl - c;
+            for (int w = 0; w < wave; ++w) base += wtot[w];
+            hist[tid] = base;
+            if (c) gbase[tid] = bin_start[b0 + tid] + atomicAdd(&cursor[b0 + tid], c) - base;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            if (r[q].w >= 0) *reinterpret_cast<int4 *>(sorted + hist[r[q].w - b0] + rank[q]) = r[q];
+        __syncthreads();
+        const int total = (int)(c1 - c0);
+        for (int i = tid; i < total; i += 1024) {
+            const int4 x = *reinterpret_cast<const int4 *>(sorted + i);
+            *reinterpret_cast<int4 *>(recs + gbase[x.w - b0] + i) = x;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
                int64_t uv_stride, const int64_t *wbin)
 {
@@ -251,6 +416,46 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     int64_t need = (n + 16383) / 16384;
     if (need < 1) need = 1;
     if (blocks > need) blocks = (int)need;
+
+    // two-level scatter: large streams whose histogram fits one LDS window
+    int shift = 6;
+    while (((g.nbins + (1 << shift) - 1) >> shift) > 1024) ++shift;
+    const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
+    const bool two_level = lds_hist && windows == 1 &&
+                           (ctx->opt.prepass == 2 || (ctx->opt.prepass == 0 && n >= ((int64_t)1 << 22)));
+    if (two_level) {
+        GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)n * sizeof(VisRec)));
+        GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));
+        int32_t *ccur = (int32_t *)ctx->blockhist.ptr;
+        VisRec *tmp = (VisRec *)ctx->recs_tmp.ptr;
+        if (!(ctx->attr_mask & 2u)) {
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse_scatter_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine_scatter_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+            ctx->attr_mask |= 2u;
+        }
+        GH_CHECK_HIP(ctx, hipMemsetAsync(ccur, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
+                           uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, 0, g.nbins);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
+                           t.work_start, t.cursor);
+        const size_t coarse_lds = (size_t)COARSE_CHUNK * sizeof(VisRec) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
+        int cblocks = ctx->num_cu * 2;
+        int64_t cneed = (n + 4 * COARSE_CHUNK - 1) / (4 * COARSE_CHUNK);
+        if (cblocks > cneed) cblocks = (int)(cneed < 1 ? 1 : cneed);
+        hipLaunchKernelGGL(coarse_scatter_kernel, dim3(cblocks), dim3(1024), coarse_lds, ctx->stream, g, n, u, v,
+                           uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp);
+        const size_t fine_lds = (size_t)COARSE_CHUNK * sizeof(VisRec) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
+        int fblocks = ctx->num_cu * 2;
+        if (fblocks > cneed) fblocks = (int)(cneed < 1 ? 1 : cneed);
+        hipLaunchKernelGGL(fine_scatter_kernel, dim3(fblocks), dim3(1024), fine_lds, ctx->stream, g, t.bin_start,
+                           t.cursor, shift, tmp, (VisRec *)ctx->recs.ptr);
+        GH_CHECK_HIP(ctx, hipGetLastError());
+        return GRIDHIP_OK;
+    }
 
     if (lds_hist) {
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)blocks * g.nbins * sizeof(int32_t)));

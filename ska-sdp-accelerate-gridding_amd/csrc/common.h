@@ -42,7 +42,7 @@ struct Geom {
 };
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0;
 };
 
 struct Workspace {
@@ -63,6 +63,7 @@ struct gridhip_ctx {
     gridhip::Workspace tables;  // bin_count / bin_start / work_start / cursors / scalars
     gridhip::Workspace stage;   // staging for the host-pointer entry points
     gridhip::Workspace sorted;  // sorted-list scratch of the tap-reusing tile kernel (tile_sorted.hip)
+    gridhip::Workspace recs_tmp;   // coarse-binned records between the two scatter levels of the pre-pass (bin.hip)
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
     int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=last call's n; 16 ints
     int num_cu = 256;

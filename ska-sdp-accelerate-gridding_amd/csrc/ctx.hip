@@ -234,7 +234,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     fft_release(ctx);
-    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted};
+    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -282,6 +282,7 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "variant")) return &ctx->opt.variant;
     if (!strcmp(key, "sort")) return &ctx->opt.sort;
     if (!strcmp(key, "dbg")) return &ctx->opt.dbg;
+    if (!strcmp(key, "prepass")) return &ctx->opt.prepass;
     return nullptr;
 }
 

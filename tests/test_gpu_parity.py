@@ -96,6 +96,44 @@ def test_sorted_variant_matches_oracle(ctx, oracle, dist):
         assert rel(got, ref) < TOL
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 8, 8, 15, 15, 20000, {}), (128, 96, 2, 2, 5, 9, 5000, {}),
+                                   (300, 300, 16, 8, 15, 15, 150000, {"sort": 1}),
+                                   (1024, 1024, 8, 2, 7, 7, 200000, {"tile": 16, "wgroups": 8}),  # 34 848 bins: 35 per coarse bin
+                                   (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 32, "wgroups": 8}),
+                                   (64, 64, 1, 1, 1, 1, 1000, {}), (200, 200, 2, 2, 31, 31, 2000, {})])
+@pytest.mark.parametrize("dist", ["uniform", "core"])
+def test_two_level_prepass(ctx, oracle, shape, dist):
+    """The scatter of the binning pre-pass in two levels (LDS-sorted runs into coarse bins, then to the bins):
+    automatic from 2^22 visibilities, forced here on small streams.  Coordinates spill over the grid edges
+    (dropped visibilities leave holes in neither level) and some wbins are out of range."""
+    N, M, W, Q, gh, gw, n, opts = shape
+    gcf, u, v, wb, vis = case(1234 + N, N, M, W, Q, gh, gw, n, spread=0.6, dist=dist)
+    wb = wb.copy()
+    wb[::97] = W + 3      # dropped and counted
+    wb[5::101] = -1
+    keep = (wb >= 0) & (wb < W)
+    ref = oracle.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), u[keep], v[keep], wb[keep], vis[keep], mt_mode=1)
+    try:
+        ctx.set_option("prepass", 2)
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        got = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
+        dropped = ctx.last_dropped()
+        d = ctx.degrid2(gcf, ref, (u, v, None), wb)
+        ctx.set_option("prepass", 1)
+        ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
+        dropped_one_level = ctx.last_dropped()
+    finally:
+        for k in ("prepass", "tile", "wgroups", "sort"):
+            ctx.set_option(k, 0)
+    assert rel(got, ref) < TOL
+    # (a bad wbin is only counted when the coordinates are inside the grid)
+    assert 0 < dropped <= int((~keep).sum()) and dropped == dropped_one_level
+    dref = oracle.degrid2(gcf, ref, u[keep], v[keep], wb[keep])
+    assert rel(d[keep], dref) < TOL
+    assert np.all(d[~keep] == 0)
+
+
 @pytest.mark.parametrize("opts", [{"tile": 16, "wgroups": 4}, {"tile": 16, "wgroups": 8}, {"tile": 8, "wgroups": 8}])
 def test_many_bins_windowed_prepass(ctx, oracle, opts):
     """More bins than one LDS histogram holds: the pre-pass covers them in windows (2 and 4 windows here),
