@@ -130,72 +130,83 @@ __global__ void __launch_bounds__(256) bin_offsets_kernel(int nbins, int nblocks
     }
 }
 
-// Single work-group scan (nbins is at most a few hundred thousand).
+// Single work-group scans (nbins is at most a few hundred thousand).
 // bin_start  : exclusive scan of bin_count over all bins (group-major order)
 // work_start : per group, exclusive scan of ceil(count/chunk) over that group's tiles
+// Each trip covers 4096 entries, four consecutive ones per thread (a wave reads 1 KB contiguous), with a
+// wave-level scan and one LDS exchange of the 16 wave totals.
+__device__ __forceinline__ int block_exclusive_scan_1024(int sum, int32_t *wtot, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();  // wtot free again
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = incl - sum, all = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int t = wtot[w];
+        if (w < wave) base += t;
+        all += t;
+    }
+    *total = all;
+    return base;
+}
+
 __global__ void __launch_bounds__(1024) bin_scan_kernel(Geom g, const int32_t *__restrict__ bin_count,
                                                         int32_t *__restrict__ bin_start,
                                                         int32_t *__restrict__ work_start,
                                                         int32_t *__restrict__ cursor)
 {
-    __shared__ int32_t part[1024];
-    __shared__ int32_t carry;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ int32_t wtot[16];
+    const int tid = threadIdx.x;
     // ---- bin_start over all bins
     {
-        const int per = (g.nbins + nt - 1) / nt;
-        const int lo = tid * per, hi = min(lo + per, g.nbins);
-        int s = 0;
-        for (int i = lo; i < hi; ++i) s += bin_count[i];
-        part[tid] = s;
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int i = 0; i < nt; ++i) {
-                int t = part[i];
-                part[i] = acc;
-                acc += t;
+        int carry = 0;
+        for (int base = 0; base < g.nbins; base += 4096) {
+            const int i0 = base + tid * 4;
+            int c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = i0 + q < g.nbins ? bin_count[i0 + q] : 0;
+            int total;
+            int acc = carry + block_exclusive_scan_1024(c[0] + c[1] + c[2] + c[3], wtot, &total);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q < g.nbins) {
+                    bin_start[i0 + q] = acc;
+                    cursor[i0 + q] = 0;
+                }
+                acc += c[q];
             }
-            bin_start[g.nbins] = acc;
+            carry += total;
         }
-        __syncthreads();
-        int acc = part[tid];
-        for (int i = lo; i < hi; ++i) {
-            bin_start[i] = acc;
-            cursor[i] = 0;
-            acc += bin_count[i];
-        }
-        __syncthreads();
+        if (tid == 0) bin_start[g.nbins] = carry;
     }
     // ---- work_start per group
     for (int grp = 0; grp < g.ngroups; ++grp) {
         const int32_t *cnt = bin_count + (size_t)grp * g.ntiles;
         int32_t *ws = work_start + (size_t)grp * (g.ntiles + 1);
-        const int per = (g.ntiles + nt - 1) / nt;
-        const int lo = tid * per, hi = min(lo + per, g.ntiles);
-        int s = 0;
-        for (int i = lo; i < hi; ++i) s += (cnt[i] + g.chunk - 1) / g.chunk;
-        part[tid] = s;
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int i = 0; i < nt; ++i) {
-                int t = part[i];
-                part[i] = acc;
-                acc += t;
+        int carry = 0;
+        for (int base = 0; base < g.ntiles; base += 4096) {
+            const int i0 = base + tid * 4;
+            int c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = i0 + q < g.ntiles ? (cnt[i0 + q] + g.chunk - 1) / g.chunk : 0;
+            int total;
+            int acc = carry + block_exclusive_scan_1024(c[0] + c[1] + c[2] + c[3], wtot, &total);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q < g.ntiles) ws[i0 + q] = acc;
+                acc += c[q];
             }
-            ws[g.ntiles] = acc;
-            carry = acc;
+            carry += total;
         }
-        __syncthreads();
-        int acc = part[tid];
-        for (int i = lo; i < hi; ++i) {
-            ws[i] = acc;
-            acc += (cnt[i] + g.chunk - 1) / g.chunk;
-        }
-        __syncthreads();
+        if (tid == 0) ws[g.ntiles] = carry;
     }
-    (void)carry;
 }
 
 template <bool LDS_HIST>
