@@ -428,12 +428,11 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     if (need < 1) need = 1;
     if (blocks > need) blocks = (int)need;
 
-    // two-level scatter: large streams whose histogram fits one LDS window
+    // two-level scatter for large streams (only the counting sweep needs the histogram windows)
     int shift = 6;
     while (((g.nbins + (1 << shift) - 1) >> shift) > 1024) ++shift;
     const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
-    const bool two_level = lds_hist && windows == 1 &&
-                           (ctx->opt.prepass == 2 || (ctx->opt.prepass == 0 && n >= ((int64_t)1 << 22)));
+    const bool two_level = lds_hist && (ctx->opt.prepass == 2 || (ctx->opt.prepass == 0 && n >= ((int64_t)1 << 22)));
     if (two_level) {
         GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)n * sizeof(VisRec)));
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));
@@ -449,8 +448,11 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             ctx->attr_mask |= 2u;
         }
         GH_CHECK_HIP(ctx, hipMemsetAsync(ccur, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, 0, g.nbins);
+        for (int wdw = 0; wdw < windows; ++wdw) {
+            const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
+            hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
+                               v, uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi);
+        }
         hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                            t.work_start, t.cursor);
         const size_t coarse_lds = (size_t)COARSE_CHUNK * sizeof(VisRec) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);

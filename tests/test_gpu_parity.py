@@ -100,6 +100,7 @@ def test_sorted_variant_matches_oracle(ctx, oracle, dist):
                                    (300, 300, 16, 8, 15, 15, 150000, {"sort": 1}),
                                    (1024, 1024, 8, 2, 7, 7, 200000, {"tile": 16, "wgroups": 8}),  # 34 848 bins: 35 per coarse bin
                                    (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 32, "wgroups": 8}),
+                                   (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 16, "wgroups": 8}),  # 4 counting windows, 136 coarse-bin width
                                    (64, 64, 1, 1, 1, 1, 1000, {}), (200, 200, 2, 2, 31, 31, 2000, {})])
 @pytest.mark.parametrize("dist", ["uniform", "core"])
 def test_two_level_prepass(ctx, oracle, shape, dist):
