@@ -40,6 +40,18 @@ def alg_bytes_per_vis(S):
     return 40 + 48 * S * S
 
 
+def lds_atomic_cycles_per_vis(S):
+    """LDS cycles the accumulate loop needs per visibility: two ds_add_f64 (re, im) per step of 64 taps, 8 cycles
+    per 64-lane instruction, 7 with three 16-lane groups active, 6 with two or fewer (measured:
+    tools/micro/lds_atomic.hip, profiles/r01_lds_atomic_microbench.txt)."""
+    taps = S * S
+    full, tail = divmod(taps, 64)
+    cyc = full * 2 * 8
+    if tail:
+        cyc += 2 * (6 if tail <= 32 else 7 if tail <= 48 else 8)
+    return cyc
+
+
 def synth_kernels(W, Q, S, device):
     """Deterministic smooth complex kernels exp(-r^2/sigma^2) * exp(i*phi(w, r))."""
     j = torch.arange(S, dtype=torch.float64, device=device) - S // 2
@@ -210,6 +222,11 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         total_vis = n * world
         k_avg = float(np.mean(ker_ms))
+        props = torch.cuda.get_device_properties(device)
+        clock_ghz = getattr(props, "clock_rate", 2_400_000) / 1e6
+        floor_ms = n * lds_atomic_cycles_per_vis(S) / props.multi_processor_count / (clock_ghz * 1e9) * 1e3
+        lds_floor = {"cycles_per_vis": lds_atomic_cycles_per_vis(S), "cus": props.multi_processor_count,
+                     "clock_GHz": clock_ghz, "floor_ms": floor_ms, "frac": floor_ms / k_avg}
         achieved = alg_bytes_per_vis(S) * n / (k_avg * 1e-3) / 1e9
         out = {
             "metric": "Mvis/s gridded (w-proj, 4096^2 grid)" if args.workload == "cfg3" else "Mvis/s gridded (w-proj)",
@@ -242,6 +259,8 @@ def main():
                 "kernel_ms_avg": k_avg,
                 "prepass_ms_avg": float(np.mean(pre_ms)),
                 "kernel_Mvis_per_s": n / (k_avg * 1e-3) / 1e6,
+                # what actually binds the kernel: the LDS atomic unit, one per CU
+                "lds_atomic": lds_floor,
             },
         }
         if world == 1 and not args.no_cpu:

@@ -19,7 +19,7 @@ gcf = bench.synth_kernels(W, Q, S, dev)
 u, v, wb, vis = bench.synth_vis(n, N, W, S, 0x5EEDC0DE, dev)
 G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
 ctx.enable_timing(True)
-names = ["fetch+init/wait", "histogram", "scan", "scatter+gather", "accumulate(wave0)", "wait slowest", "flush"]
+names = ["work fetch + waiting at barriers", "histogram", "scan", "scatter + value gather", "accumulate walk", "waiting for the slowest wave", "flush + clear"]
 for s in sets:
     for kv in filter(None, s.split(",")):
         k, val = kv.split("=")
@@ -30,9 +30,12 @@ for s in sets:
     ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
     t = ctx.last_timing()
     cyc = [ctx.get_option(f"prof{i}") for i in range(7)]
-    tot = sum(cyc)
-    print(f"[{s or 'default'}] kernel {t[2]:.2f} ms; share of work-group time per phase:")
-    for nm, c in zip(names, cyc):
-        print(f"  {nm:20s} {100.0 * c / tot:6.2f} %   ({t[2] * c / tot:6.2f} ms)")
+    # phases 0..3 are stamped by the sorter wave, 4..6 by walker wave 0: each role's stamps add up to the
+    # work-group's whole time
+    for role, idx in (("sorter wave", (0, 1, 2, 3)), ("walker wave 0", (4, 5, 6))):
+        tot = sum(cyc[i] for i in idx) or 1
+        print(f"[{s or 'default'}] kernel {t[2]:.2f} ms; {role}: share of its time per phase")
+        for i in idx:
+            print(f"  {names[i]:28s} {100.0 * cyc[i] / tot:6.2f} %   ({t[2] * cyc[i] / tot:6.2f} ms)")
     wv = [ctx.get_option(f"prof{8 + i}") for i in range(16)]
     print("  walk time per wave (relative to the slowest): " + " ".join(f"{x / max(wv):.2f}" for x in wv))
