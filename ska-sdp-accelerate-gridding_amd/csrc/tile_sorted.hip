@@ -57,7 +57,12 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
     extern __shared__ double lds[];
     constexpr int S2 = S * S;
     constexpr int NSTEP = (S2 + 63) / 64;
-    constexpr int TAIL = S2 - (NSTEP - 1) * 64;
+    constexpr int TAIL0 = S2 - (NSTEP - 1) * 64;
+    // A last step with 33 or 34 taps keeps 32 of them: an LDS atomic with at most two 16-lane groups active costs
+    // 6 cycles instead of 7.  The one or two taps left over are added once per block of 64 records, every lane for
+    // its own record (gridding only; 15x15: 62 -> 60.25 LDS cycles per visibility).
+    constexpr int EXTRA = (!DEGRID && TAIL0 > 32 && TAIL0 <= 34) ? TAIL0 - 32 : 0;
+    constexpr int TAIL = TAIL0 - EXTRA;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int plane = g.lrows * g.ldw;
@@ -251,6 +256,12 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             const uint32_t mykey = mo.x >> 16;
             const uint32_t prevkey = (uint32_t)__shfl_up((int)mykey, 1, 64);
             unsigned long long bits = __ballot(lane < bcnt && (lane == 0 || mykey != prevkey));  // run starts
+            double2 kx[EXTRA > 0 ? EXTRA : 1];
+            if (EXTRA > 0) {  // this lane's record: the taps its run steps leave out (used after the block's runs)
+                const double2 *kp = gcf + (size_t)(first_slice + min((int)mykey, nkeys - 1)) * S2 + (S2 - EXTRA);
+#pragma unroll
+                for (int e = 0; e < EXTRA; ++e) kx[e] = (ABL & 4) ? make_double2(1.0, 2.0) : kp[e];
+            }
             int lastKey = 0;
             // next run of the block: its slice, first lane and length (an empty run once the block is used up)
             auto advance = [&](int &key, int &start, int &len) {
@@ -348,6 +359,18 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
             // The last two prefetches stay "used" on the exit path (in a branch that is never taken: done
             // equals bcnt here), so LLVM cannot sink them below the exit test, and nothing waits for them.
             if (done > bcnt) asm volatile("" ::"v"(kA[0].x), "v"(kA[NSTEP - 1].y), "v"(kB[0].x), "v"(kB[NSTEP - 1].y));
+            if (EXTRA > 0 && !(ABL & 1) && lane < bcnt) {
+                const int lb = (int)((mo.x >> 8) & 0xff) * g.ldw + (int)(mo.x & 0xff);
+#pragma unroll
+                for (int e = 0; e < EXTRA; ++e) {
+                    const int t = S2 - EXTRA + e;
+                    double *cell = lre + (lb + (t / S) * g.ldw + (t % S));
+                    __hip_atomic_fetch_add(cell, vB.x * kx[e].x - vB.y * kx[e].y, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, vB.x * kx[e].y + vB.y * kx[e].x, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     };
 
