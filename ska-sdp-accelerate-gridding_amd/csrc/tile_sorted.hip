@@ -277,11 +277,11 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                 key = lastKey = (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, start) >> 16);
             };
             auto process = [&](const double2(&k)[NSTEP], int start, int len) {
-                for (int i = 0; i < len; ++i) {
-                    const int j = start + i;
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
-                    const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
-                    if (!DEGRID) {
+                if (!DEGRID) {
+                    for (int i = 0; i < len; ++i) {
+                        const int j = start + i;
+                        const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
+                        const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
                         const double vx = readlane_f64(vB.x, j), vy = readlane_f64(vB.y, j);
 #pragma unroll
                         for (int s = 0; s < NSTEP; ++s) {
@@ -293,28 +293,48 @@ __global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const Vi
                                 continue;
                             }
                             // the last step's idle lanes are switched off (EXEC): an LDS atomic costs 8 cycles with
-                            // all four 16-lane groups active, 7 with three (tools/micro/lds_atomic.hip)
+                            // all four 16-lane groups active, 7 with three, 6 with two (tools/micro/lds_atomic.hip)
                             if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
                                 __hip_atomic_fetch_add(cell, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, im, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                         }
-                    } else {
-                        const int32_t o = __builtin_amdgcn_readlane((int)mo.y, j);
-                        double sr = 0.0, si = 0.0;
+                    }
+                } else {
+                    // four visibilities of the run at a time: their partial sums are reduced across the wave
+                    // together (wave_sum4_rows), the results land in lanes 15, 31, 47 and 63
+                    for (int i = 0; i < len; i += 4) {
+                        double sr[4], si[4];
+                        int32_t oo[4];
 #pragma unroll
-                        for (int s = 0; s < NSTEP; ++s) {
-                            const double *cell = lre + (lbase + loff[s]);
-                            if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
-                                const double gr = cell[0], gi = cell[SORTED_IM_OFF / 8];
-                                sr += k[s].x * gr - k[s].y * gi;
-                                si += k[s].x * gi + k[s].y * gr;
+                        for (int q = 0; q < 4; ++q) {
+                            sr[q] = 0.0;
+                            si[q] = 0.0;
+                            oo[q] = 0;
+                            if (i + q < len) {  // uniform
+                                const int j = start + i + q;
+                                const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
+                                const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+                                oo[q] = __builtin_amdgcn_readlane((int)mo.y, j);
+#pragma unroll
+                                for (int s = 0; s < NSTEP; ++s) {
+                                    const double *cell = lre + (lbase + loff[s]);
+                                    if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
+                                        const double gr = cell[0], gi = cell[SORTED_IM_OFF / 8];
+                                        sr[q] += k[s].x * gr - k[s].y * gi;
+                                        si[q] += k[s].x * gi + k[s].y * gr;
+                                    }
+                                }
                             }
                         }
-                        sr = wave_sum_lane63(sr);
-                        si = wave_sum_lane63(si);
-                        if (lane == 63) vis[o] = make_double2(sr, si);
+                        const double rr = wave_sum4_rows(sr[0], sr[1], sr[2], sr[3]);
+                        const double ri = wave_sum4_rows(si[0], si[1], si[2], si[3]);
+                        const int row = lane >> 4;
+                        if ((lane & 15) == 15 && i + row < len) {
+                            const int32_t o = row == 0 ? oo[0] : row == 1 ? oo[1] : row == 2 ? oo[2] : oo[3];
+                            vis[o] = make_double2(rr, ri);
+                        }
                     }
                 }
             };
