@@ -70,11 +70,16 @@ int gridhip_synchronize(gridhip_ctx *ctx);
 /* Tuning knobs (all have defaults chosen per shape):
  *   "tile"      grid-tile side T in cells (power of two, 8..128; 0 = auto)
  *   "block"     threads per work-group of the tile kernels (multiple of 64, <=1024; 0 = auto)
- *   "chunk"     max visibilities per work item (0 = auto)
+ *   "chunk"     max visibilities per work item (0 = auto; the sorted kernel takes at most 16384)
  *   "wgroups"   number of w-plane groups work items are split into for XCD/L2 locality (1..8; 0 = auto)
  *   "variant"   0 = LDS-tile accumulate (default), 1 = direct global-atomic scatter (baseline)
- *   "sort"      order each work item's records by kernel slice in LDS so that runs of visibilities
+ *   "sort"      order each work item's records by kernel slice so that runs of visibilities
  *               reuse their taps from registers: 0 = auto, 1 = on (when the shape allows), 2 = off
+ *   "prepass"   scatter of the binning pre-pass: 0 = auto (two levels from 2^22 visibilities), 1 = one level,
+ *               2 = two levels (LDS-sorted runs into coarse bins, then into the bins)
+ *   "dbg"       ablation / profiling switch for tuning runs (0 = off; results are wrong with most values)
+ * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel
+ * launch (expected 0); "prof0".."prof31" = cycle counters of a dbg=16 launch (tools/phase_profile.py).
  */
 int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value);
 int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value);
