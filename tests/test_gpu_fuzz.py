@@ -42,13 +42,14 @@ def make_case(seed):
     if rng.random() < 0.5:
         opts["chunk"] = int(rng.choice([64, 100, 1000, 5000]))
     opts["sort"] = int(rng.choice([0, 1, 2]))
+    opts["prepass"] = int(rng.choice([0, 1, 2]))  # one- or two-level scatter in the binning pre-pass
     return (H, Wd, gcf, u, v, wb, vis, opts)
 
 
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_convgrid2_and_degrid2(ctx, oracle, seed):
     H, Wd, gcf, u, v, wb, vis, opts = make_case(seed)
-    keys = ("tile", "block", "wgroups", "chunk", "sort")
+    keys = ("tile", "block", "wgroups", "chunk", "sort", "prepass")
     G0 = np.zeros((H, Wd), dtype=np.complex128)
     ref = oracle.convgrid2(gcf, G0.copy(), u, v, wb, vis)
     rng = np.random.default_rng(seed)

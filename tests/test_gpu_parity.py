@@ -65,7 +65,10 @@ def test_convgrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
 @pytest.mark.parametrize("tile,block,wgroups,chunk,sort", [(8, 64, 1, 64, 0), (16, 256, 2, 100, 0), (32, 512, 4, 512, 0),
                                                            (64, 1024, 8, 4096, 2), (64, 256, 1, 0, 2), (32, 1024, 8, 64, 0),
                                                            (64, 1024, 8, 0, 1), (64, 1024, 1, 0, 1), (32, 512, 4, 700, 1),
-                                                           (64, 256, 2, 0, 1), (16, 128, 8, 0, 1)])
+                                                           (64, 256, 2, 0, 1), (16, 128, 8, 0, 1),
+                                                           (64, 64, 2, 0, 1),     # one wave: sorter and walker in turn
+                                                           (64, 128, 8, 300, 1),  # one walker + the sorter
+                                                           (32, 1024, 1, 16384, 1)])
 def test_tuning_knobs_do_not_change_results(ctx, oracle, tile, block, wgroups, chunk, sort):
     N, W, Q, S, n = 200, 8, 4, 15, 30000
     gcf, u, v, wb, vis = case(99, N, N, W, Q, S, S, n)
