@@ -126,6 +126,142 @@ __global__ void aw_vis_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int32
     conv_same_T(la, lb, S, out, true);
 }
 
+
+// The same per-visibility kernels for a compile-time support, organised for the vector ALU: a wave takes four
+// visibilities at a time, lane = (visibility v, column x), and every lane keeps out[y][x] for all S rows y in
+// registers.  For each row i of the pair kernel the lane holds a[i][0..S) in registers (fetched one row ahead)
+// and, for every y whose w-kernel row r = y - i + c exists, adds sum_j a[i][j] * b[r][x + c - j]; b comes
+// from an LDS copy of the w-kernel slice padded with c zero columns on both sides, so the inner loops have
+// no bounds logic and skip whole rows only (uniformly).  One LDS read and four FMAs per complex product
+// against two reads, the FMAs and ~8 address/loop instructions in the generic kernel above.
+template <int S>
+__global__ void __launch_bounds__(256) aw_vis_rows_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int32_t Q,
+                                                          int64_t A, const double2 *__restrict__ wkerns,
+                                                          const double2 *__restrict__ pairk,
+                                                          const int32_t *__restrict__ slot,
+                                                          const double *__restrict__ u, const double *__restrict__ v,
+                                                          int64_t stride, const int64_t *__restrict__ wbin,
+                                                          const int64_t *__restrict__ a1,
+                                                          const int64_t *__restrict__ a2, double2 *__restrict__ kperv,
+                                                          int32_t *__restrict__ scalars)
+{
+    constexpr int C = S / 2, PW = S + 2 * C, S2 = S * S;
+    static_assert(S <= 16, "one 16-lane row per visibility");
+    extern __shared__ double2 sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v4 = lane >> 4, x = lane & 15;
+    double2 *bp = sm + (size_t)(wave * 4 + v4) * S * PW;  // this visibility's padded w-kernel slice
+    const int64_t groups = (n + 3) / 4;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t k = grp * 4 + v4;
+        const bool have = k < n;
+        int64_t wb = 0, p = 0, q = 0;
+        double pu = 0.0, pv = 0.0;
+        if (have) {
+            wb = wbin[k];
+            p = a1[k];
+            q = a2[k];
+            pu = u[k * stride];
+            pv = v[k * stride];
+        }
+        const bool bad = wb < 0 || wb >= W || p < 0 || p >= A || q < 0 || q >= A || !(pu == pu) || !(pv == pv);
+        const bool live = have && !bad;
+        int64_t cx = 0, cy = 0;
+        int32_t xf = 0, yf = 0;
+        if (live) {
+            frac_coord_dev(Wd, Q, pu, &cx, &xf);
+            frac_coord_dev(H, Q, pv, &cy, &yf);
+        }
+        const double2 *wk = wkerns + (live ? ((size_t)(wb * Q + yf) * Q + xf) * S2 : 0);
+        const double2 *pk = pairk + (live ? (size_t)slot[p * A + q] * S2 : 0);
+        // padded copy of the slice: row r, padded column pc holds b[r][pc - C]
+        __builtin_amdgcn_wave_barrier();  // (the previous group's reads of this LDS region are done: same wave)
+        {   // all of the lane's loads first, then its LDS stores (a load-store loop would pay the memory latency per trip)
+            constexpr int NE = (S * PW + 15) / 16;
+            double2 stage[NE];
+#pragma unroll
+            for (int t = 0; t < NE; ++t) {
+                const int e = x + 16 * t;
+                const int r = e / PW, pc = e - r * PW, cc = pc - C;
+                stage[t] = (live && e < S * PW && cc >= 0 && cc < S) ? wk[r * S + cc] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int t = 0; t < NE; ++t) {
+                const int e = x + 16 * t;
+                if (e < S * PW) bp[e] = stage[t];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // acc[r] belongs to output row y = r + i - C while pair-kernel row i is being applied (it meets w-kernel
+        // row r there); after each i the array moves down by one and the row that has just received its last
+        // contribution leaves.  So every index below is a compile-time constant.
+        double2 acc[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) acc[r] = make_double2(0.0, 0.0);
+        double2 *out = kperv + (size_t)(have ? k : 0) * S2 + (size_t)x * S;  // out[x * S + y]: comes out transposed
+        const bool store = have && x < S;
+        double2 arow[S], anext[S], b0[S], b1[S];  // b0 / b1: w-kernel row r for even / odd r, one fetched ahead
+#pragma unroll
+        for (int j = 0; j < S; ++j) anext[j] = pk[j];
+        for (int i = 0; i < S; ++i) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) arow[j] = anext[j];
+            if (i + 1 < S) {
+#pragma unroll
+                for (int j = 0; j < S; ++j) anext[j] = pk[(i + 1) * S + j];
+            }
+            const int rlo = max(0, C - i), rhi = min(S - 1, S - 1 + C - i);  // rows r whose y = r + i - C exists
+            {
+                const double2 *brow = bp + rlo * PW + (x + 2 * C);  // b[r][x + C - j] = brow[-j]
+                if (rlo & 1) {
+#pragma unroll
+                    for (int j = 0; j < S; ++j) b1[j] = brow[-j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < S; ++j) b0[j] = brow[-j];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                if (r < rlo || r > rhi) continue;  // uniform
+                double2(&bc)[S] = (r & 1) ? b1 : b0;
+                double2(&bn)[S] = (r & 1) ? b0 : b1;
+                if (r + 1 <= rhi) {
+                    const double2 *brow = bp + (r + 1) * PW + (x + 2 * C);
+#pragma unroll
+                    for (int j = 0; j < S; ++j) bn[j] = brow[-j];
+                }
+                // four independent chains (one FMA each per product): with one wave per SIMD nothing else hides
+                // the FMA latency
+                double pr = 0.0, qr = 0.0, pi = 0.0, qi = 0.0;
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    pr = fma(arow[j].x, bc[j].x, pr);
+                    qr = fma(arow[j].y, bc[j].y, qr);
+                    pi = fma(arow[j].x, bc[j].y, pi);
+                    qi = fma(arow[j].y, bc[j].x, qi);
+                }
+                acc[r].x += pr - qr;
+                acc[r].y += pi + qi;
+            }
+            // acc[0] is row y = i - C: complete when that exists
+            if (i >= C && store) out[i - C] = live ? make_double2(acc[0].x, -acc[0].y) : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int r = 0; r + 1 < S; ++r) acc[r] = acc[r + 1];
+            acc[S - 1] = make_double2(0.0, 0.0);
+        }
+        // after the shift that followed i = S-1, acc[r] is row y = r + S - C
+        if (store) {
+#pragma unroll
+            for (int r = 0; r + S - C < S; ++r)
+                out[r + S - C] = live ? make_double2(acc[r].x, -acc[r].y) : make_double2(0.0, 0.0);
+            if (bad && x == 0 && (pu == pu) && (pv == pv)) atomicAdd(&scalars[1], 1);
+        }
+    }
+}
+
 }  // namespace gridhip
 
 using namespace gridhip;
@@ -191,6 +327,21 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
     AW_HIP(hipMalloc(&dkperv, (size_t)batch * S2 * 16));
     for (int64_t lo = 0; lo < n; lo += batch) {
         const int64_t m = n - lo < batch ? n - lo : batch;
+        if (S == 15) {
+            constexpr int S_ = 15;
+            const size_t rows_lds = (size_t)16 * S_ * (S_ + 2 * (S_ / 2)) * sizeof(double2);  // 16 padded slices
+            if (!(ctx->attr_mask & 4u)) {
+                AW_HIP(hipFuncSetAttribute((const void *)aw_vis_rows_kernel<S_>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+                ctx->attr_mask |= 4u;
+            }
+            int64_t rblocks = (m + 15) / 16;
+            if (rblocks > ctx->num_cu) rblocks = ctx->num_cu;
+            hipLaunchKernelGGL(aw_vis_rows_kernel<S_>, dim3((unsigned)rblocks), dim3(256), rows_lds, ctx->stream, H, Wd,
+                               m, W, (int32_t)Q, A, (const double2 *)wkerns, (const double2 *)dpairk,
+                               (const int32_t *)dslot, u + lo * uv_stride, v + lo * uv_stride, uv_stride, wbin + lo,
+                               a1 + lo, a2 + lo, (double2 *)dkperv, ctx->d_scalars);
+        } else
         hipLaunchKernelGGL(aw_vis_kernel, dim3((unsigned)m), dim3(256), lds, ctx->stream, H, Wd, m, W, (int32_t)Q,
                            (int)S, A, (const double2 *)wkerns, (const double2 *)dpairk, (const int32_t *)dslot,
                            u + lo * uv_stride, v + lo * uv_stride, uv_stride, wbin + lo, a1 + lo, a2 + lo,
