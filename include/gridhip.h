@@ -77,6 +77,11 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               reuse their taps from registers: 0 = auto, 1 = on (when the shape allows), 2 = off
  *   "prepass"   scatter of the binning pre-pass: 0 = auto (two levels from 2^22 visibilities), 1 = one level,
  *               2 = two levels (LDS-sorted runs into coarse bins, then into the bins)
+ *   "async_prepass"  1 = the coordinate arrays (u, v, wbin) given to gridhip_convgrid2_dev are complete when the
+ *               call is made (not the product of work still queued on the stream): the binning pre-pass of a call
+ *               then runs on an internal stream beside the previous call's tile kernel (two record sets
+ *               alternate); grid updates stay on the caller's stream in call order.  0 = off (default);
+ *               applies from 2^22 visibilities (2 = always)
  *   "dbg"       ablation / profiling switch for tuning runs (0 = off; results are wrong with most values)
  * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel
  * launch (expected 0); "prof0".."prof31" = cycle counters of a dbg=16 launch (tools/phase_profile.py).

@@ -24,6 +24,29 @@
 
 namespace gridhip {
 
+#ifndef LIGHT_PRIO
+#define LIGHT_PRIO 3  // wave priority of the kernels that run beside a tile kernel (async_prepass): they finish in
+                      // 5.8 ms instead of 9.8 ms, the tile kernel loses the same 1.6 ms either way
+#endif
+
+// streaming accesses of the kernels that run beside a tile kernel carry the non-temporal hint: they should not
+// displace the kernel table (L2, Infinity Cache) the tile kernel lives on
+typedef int nt_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ld_nt(const int4 *p)
+{
+    const nt_i4 a = __builtin_nontemporal_load(reinterpret_cast<const nt_i4 *>(p));
+    return make_int4(a.x, a.y, a.z, a.w);
+}
+__device__ __forceinline__ void st_nt(int4 *p, int4 v)
+{
+    nt_i4 a;
+    a.x = v.x;
+    a.y = v.y;
+    a.z = v.z;
+    a.w = v.w;
+    __builtin_nontemporal_store(a, reinterpret_cast<nt_i4 *>(p));
+}
+
 struct BinOut {
     int32_t bin;  // -1: no tap in the grid, -2: wbin outside [0,W)
     int32_t lxy, kslice;
@@ -83,6 +106,9 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
     // with more bins than that are covered by several launches, each a full sweep of the stream.
     extern __shared__ int32_t hist[];
     const int nwin = bin_hi - bin_lo;
+    // 512-thread launches run beside a tile kernel (async_prepass): few instructions, all of them feeding memory
+    // requests, so they go first at the SIMD's arbiter (which otherwise favours the tile kernel's older waves)
+    if (LIGHT_PRIO && blockDim.x == 512) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < nwin; i += blockDim.x) hist[i] = 0;
         __syncthreads();
@@ -133,9 +159,10 @@ __global__ void __launch_bounds__(256) bin_offsets_kernel(int nbins, int nblocks
 // Single work-group scans (nbins is at most a few hundred thousand).
 // bin_start  : exclusive scan of bin_count over all bins (group-major order)
 // work_start : per group, exclusive scan of ceil(count/chunk) over that group's tiles
-// Each trip covers 4096 entries, four consecutive ones per thread (a wave reads 1 KB contiguous), with a
+// Each trip covers 4 x NT entries, four consecutive ones per thread (a wave reads 1 KB contiguous), with a
 // wave-level scan and one LDS exchange of the 16 wave totals.
-__device__ __forceinline__ int block_exclusive_scan_1024(int sum, int32_t *wtot, int *total)
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan(int sum, int32_t *wtot, int *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = sum;
@@ -148,7 +175,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int sum, int32_t *wtot,
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     int base = incl - sum, all = 0;
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         const int t = wtot[w];
         if (w < wave) base += t;
         all += t;
@@ -157,7 +184,8 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int sum, int32_t *wtot,
     return base;
 }
 
-__global__ void __launch_bounds__(1024) bin_scan_kernel(Geom g, const int32_t *__restrict__ bin_count,
+template <int NT>
+__global__ void __launch_bounds__(NT) bin_scan_kernel(Geom g, const int32_t *__restrict__ bin_count,
                                                         int32_t *__restrict__ bin_start,
                                                         int32_t *__restrict__ work_start,
                                                         int32_t *__restrict__ cursor)
@@ -167,13 +195,13 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(Geom g, const int32_t *_
     // ---- bin_start over all bins
     {
         int carry = 0;
-        for (int base = 0; base < g.nbins; base += 4096) {
+        for (int base = 0; base < g.nbins; base += 4 * NT) {
             const int i0 = base + tid * 4;
             int c[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) c[q] = i0 + q < g.nbins ? bin_count[i0 + q] : 0;
             int total;
-            int acc = carry + block_exclusive_scan_1024(c[0] + c[1] + c[2] + c[3], wtot, &total);
+            int acc = carry + block_exclusive_scan<NT>(c[0] + c[1] + c[2] + c[3], wtot, &total);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (i0 + q < g.nbins) {
@@ -191,13 +219,13 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(Geom g, const int32_t *_
         const int32_t *cnt = bin_count + (size_t)grp * g.ntiles;
         int32_t *ws = work_start + (size_t)grp * (g.ntiles + 1);
         int carry = 0;
-        for (int base = 0; base < g.ntiles; base += 4096) {
+        for (int base = 0; base < g.ntiles; base += 4 * NT) {
             const int i0 = base + tid * 4;
             int c[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) c[q] = i0 + q < g.ntiles ? (cnt[i0 + q] + g.chunk - 1) / g.chunk : 0;
             int total;
-            int acc = carry + block_exclusive_scan_1024(c[0] + c[1] + c[2] + c[3], wtot, &total);
+            int acc = carry + block_exclusive_scan<NT>(c[0] + c[1] + c[2] + c[3], wtot, &total);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (i0 + q < g.ntiles) ws[i0 + q] = acc;
@@ -246,66 +274,149 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
     }
 }
 
+// ---- pre-pass beside a tile kernel (async_prepass) -------------------------------------------
+// The coordinate arithmetic (fp64 floor / round / conversions, ~100 instructions per visibility) is what a
+// co-resident pre-pass costs the tile kernel most - issue slots, not bandwidth - and the LDS the tile kernel
+// leaves (44 KB) holds a quarter of the bin histogram.  So this form does the arithmetic ONCE, leaving unbinned
+// records and a compact array of bin numbers; the histogram is then counted from the bin numbers in four
+// windows (4 x 0.4 GB, no arithmetic) and the coarse scatter reads the records instead of the coordinates.
+__global__ void __launch_bounds__(512) light_records_kernel(Geom g, int64_t n, const double *__restrict__ u,
+                                                            const double *__restrict__ v, int64_t stride,
+                                                            const int64_t *__restrict__ wbin,
+                                                            VisRec *__restrict__ raw, int32_t *__restrict__ bins,
+                                                            int32_t *__restrict__ scalars)
+{
+    if (LIGHT_PRIO) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
+    int dropped = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const BinOut b = vis_bin(g, __builtin_nontemporal_load(u + k * stride), __builtin_nontemporal_load(v + k * stride),
+                                 wbin ? __builtin_nontemporal_load(wbin + k) : 0, k);
+        if (b.bin == -2) ++dropped;
+        st_nt(reinterpret_cast<int4 *>(raw + k), make_int4(b.lxy, b.kslice, (int32_t)k, b.bin));
+        __builtin_nontemporal_store(b.bin, bins + k);
+    }
+    if (dropped) atomicAdd(&scalars[0], dropped);
+}
+
+__global__ void __launch_bounds__(512) light_count_kernel(int64_t n, const int32_t *__restrict__ bins,
+                                                          int32_t *__restrict__ bin_count, int bin_lo, int bin_hi)
+{
+    extern __shared__ int32_t hist[];
+    if (LIGHT_PRIO) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
+    const int nwin = bin_hi - bin_lo;
+    for (int i = threadIdx.x; i < nwin; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int64_t n4 = n / 4;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
+        const int4 b = ld_nt(reinterpret_cast<const int4 *>(bins) + k);
+        if (b.x >= bin_lo && b.x < bin_hi) atomicAdd(&hist[b.x - bin_lo], 1);
+        if (b.y >= bin_lo && b.y < bin_hi) atomicAdd(&hist[b.y - bin_lo], 1);
+        if (b.z >= bin_lo && b.z < bin_hi) atomicAdd(&hist[b.z - bin_lo], 1);
+        if (b.w >= bin_lo && b.w < bin_hi) atomicAdd(&hist[b.w - bin_lo], 1);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t k = n4 * 4 + threadIdx.x; k < n; k += blockDim.x) {
+            const int b = bins[k];
+            if (b >= bin_lo && b < bin_hi) atomicAdd(&hist[b - bin_lo], 1);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
+        const int c = hist[i];
+        if (c) atomicAdd(&bin_count[bin_lo + i], c);
+    }
+}
+
 // ---- two-level scatter ----------------------------------------------------------------------
-constexpr int COARSE_CHUNK = 4096;  // visibilities per LDS sort (64 KB of records: two work-groups per CU)
+// Both levels exist in two sizes: <1024 threads, 4096-record chunks> (64 KB of records in LDS, two work-groups per
+// CU) for a pre-pass that has the chip to itself, and <512, 2048> (37-41 KB of LDS, 64 registers) for one that runs
+// on a side stream BESIDE the previous call's tile kernel, whose persistent work-groups leave 44 KB of LDS, half
+// the wave slots and a quarter of the registers of every CU free (option "async_prepass").
+
+// In-place exclusive scan of hist[0..nent), nent <= 1024, by NT threads (consecutive entries per thread);
+// reserve(e, count, base) is called for every non-empty entry; wtot[16] receives the total.
+template <int NT, typename F>
+__device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *wtot, F &&reserve)
+{
+    constexpr int EPT = 1024 / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c[EPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid * EPT + k;
+        c[k] = e < nent ? hist[e] : 0;
+        sum += c[k];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid * EPT + k;
+        if (e < nent) {
+            hist[e] = base;
+            if (c[k]) reserve(e, c[k], base);
+        }
+        base += c[k];
+    }
+    if (tid == NT - 1) wtot[16] = base;
+}
 
 // Level 1.  tmp is laid out like the final record array at coarse granularity: coarse bin c owns
 // [bin_start[c << shift], bin_start[min((c + 1) << shift, nbins)]).  Each chunk reserves, per coarse bin, a
 // contiguous range there (one global atomic per chunk and non-empty coarse bin) and writes its records as
 // runs; the record's spare word carries its bin for level 2.
-__global__ void __launch_bounds__(1024) coarse_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
-                                                              const double *__restrict__ v, int64_t stride,
-                                                              const int64_t *__restrict__ wbin,
-                                                              const int32_t *__restrict__ bin_start,
-                                                              int32_t *__restrict__ ccur, int shift, int ncoarse,
-                                                              VisRec *__restrict__ tmp)
+template <int NT, int CHUNK, bool FROM_RECS = false>
+__global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
+                                                            const double *__restrict__ v, int64_t stride,
+                                                            const int64_t *__restrict__ wbin,
+                                                            const int32_t *__restrict__ bin_start,
+                                                            int32_t *__restrict__ ccur, int shift, int ncoarse,
+                                                            VisRec *__restrict__ tmp, const VisRec *__restrict__ raw)
 {
     extern __shared__ int32_t smem[];
-    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [COARSE_CHUNK]
-    int32_t *hist = smem + COARSE_CHUNK * 4;            // [ncoarse]: count, then the coarse bin's first slot in `sorted`
+    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [CHUNK]
+    int32_t *hist = smem + CHUNK * 4;                   // [ncoarse]: count, then the coarse bin's first slot in `sorted`
     int32_t *gbase = hist + ncoarse;                    // [ncoarse]: tmp position of sorted[0] if it were in this bin
     int32_t *wtot = gbase + ncoarse;                    // [16] per-wave totals of the scan, [16] = chunk total
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int PER = COARSE_CHUNK / 1024;
+    const int tid = threadIdx.x;
+    constexpr int PER = CHUNK / NT;
+    if (LIGHT_PRIO && NT == 512) __builtin_amdgcn_s_setprio(LIGHT_PRIO);  // beside a tile kernel: see bin_count_kernel
     int64_t lo, hi;
     block_range(n, &lo, &hi);
-    for (int64_t c0 = lo; c0 < hi; c0 += COARSE_CHUNK) {
-        for (int i = tid; i < ncoarse; i += 1024) hist[i] = 0;
+    for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
+        for (int i = tid; i < ncoarse; i += NT) hist[i] = 0;
         __syncthreads();
         BinOut b[PER];
         int rank[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const int64_t k = c0 + q * 1024 + tid;
+            const int64_t k = c0 + q * NT + tid;
             b[q].bin = -1;
-            if (k < hi) b[q] = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
+            if (k < hi) {
+                if (FROM_RECS) {  // (light_records_kernel has done the arithmetic)
+                    const int4 r = ld_nt(reinterpret_cast<const int4 *>(raw + k));
+                    b[q].lxy = r.x;
+                    b[q].kslice = r.y;
+                    b[q].bin = r.w;
+                } else
+                    b[q] = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
+            }
         }
 #pragma unroll
         for (int q = 0; q < PER; ++q)
             rank[q] = b[q].bin >= 0 ? atomicAdd(&hist[b[q].bin >> shift], 1) : 0;
         __syncthreads();
-        // exclusive scan of the counts (ncoarse <= 1024: one entry per thread) and the global reservations
-        {
-            const int c = tid < ncoarse ? hist[tid] : 0;
-            int incl = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) wtot[wave] = incl;
-            __syncthreads();
-            int base = incl - c;
-            for (int w = 0; w < wave; ++w) base += wtot[w];
-            if (tid < ncoarse) {
-                hist[tid] = base;
-                if (c) {
-                    const int first = tid << shift;
-                    gbase[tid] = bin_start[first] + atomicAdd(&ccur[tid], c) - base;
-                }
-            }
-            if (tid == 1023) wtot[16] = base + c;
-        }
+        // exclusive scan of the counts and the global reservations
+        scan_entries<NT>(hist, ncoarse, wtot, [&](int e, int c, int base) {
+            gbase[e] = bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
+        });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
@@ -313,89 +424,87 @@ __global__ void __launch_bounds__(1024) coarse_scatter_kernel(Geom g, int64_t n,
             VisRec r;
             r.lxy = b[q].lxy;
             r.kslice = b[q].kslice;
-            r.orig = (int32_t)(c0 + q * 1024 + tid);
+            r.orig = (int32_t)(c0 + q * NT + tid);
             r.pad = b[q].bin;
             sorted[hist[b[q].bin >> shift] + rank[q]] = r;
         }
         __syncthreads();
         const int total = wtot[16];
-        for (int i = tid; i < total; i += 1024) {
+        for (int i = tid; i < total; i += NT) {
             const int4 r = *reinterpret_cast<const int4 *>(sorted + i);
-            *reinterpret_cast<int4 *>(tmp + gbase[r.w >> shift] + i) = r;  // neighbouring lanes: neighbouring slots
+            int4 *dst = reinterpret_cast<int4 *>(tmp + gbase[r.w >> shift] + i);  // neighbouring lanes: neighbouring slots
+            if (NT == 512)
+                st_nt(dst, r);
+            else
+                *dst = r;
         }
         __syncthreads();
     }
 }
 
-// Level 2.  Work-group w takes the w-th equal share of tmp in chunks of COARSE_CHUNK records.  tmp is ordered by
+// Level 2.  Work-group w takes the w-th equal share of tmp in chunks of CHUNK records.  tmp is ordered by
 // coarse bin, so a chunk's bins lie between the coarse bins of its first and last record: normally one or two
 // coarse bins, i.e. at most a few hundred bins.  The chunk is counting-sorted by bin in LDS exactly as level 1 sorts
 // by coarse bin, each bin's range is reserved with one global atomic, and the records leave as runs.  A chunk that
 // spans more than 1024 bins (very sparse regions) falls back to one global atomic per record.
-__global__ void __launch_bounds__(1024) fine_scatter_kernel(Geom g, const int32_t *__restrict__ bin_start,
-                                                            int32_t *__restrict__ cursor, int shift,
-                                                            const VisRec *__restrict__ tmp, VisRec *__restrict__ recs)
+template <int NT, int CHUNK>
+__global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) fine_scatter_kernel(Geom g, const int32_t *__restrict__ bin_start,
+                                                          int32_t *__restrict__ cursor, int shift,
+                                                          const VisRec *__restrict__ tmp, VisRec *__restrict__ recs)
 {
     extern __shared__ int32_t smem[];
-    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [COARSE_CHUNK]
-    int32_t *hist = smem + COARSE_CHUNK * 4;            // [1024]
+    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [CHUNK]
+    int32_t *hist = smem + CHUNK * 4;                   // [1024]
     int32_t *gbase = hist + 1024;                       // [1024]
     int32_t *wtot = gbase + 1024;                       // [17]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int PER = COARSE_CHUNK / 1024;
+    const int tid = threadIdx.x;
+    constexpr int PER = CHUNK / NT;
+    if (LIGHT_PRIO && NT == 512) __builtin_amdgcn_s_setprio(LIGHT_PRIO);  // beside a tile kernel: see bin_count_kernel
     const int64_t ntot = bin_start[g.nbins];
     int64_t per = (ntot + gridDim.x - 1) / gridDim.x;
-    per = (per + COARSE_CHUNK - 1) / COARSE_CHUNK * COARSE_CHUNK;
+    per = (per + CHUNK - 1) / CHUNK * CHUNK;
     const int64_t lo = min((int64_t)blockIdx.x * per, ntot), hi = min(lo + per, ntot);
-    for (int64_t c0 = lo; c0 < hi; c0 += COARSE_CHUNK) {
-        const int64_t c1 = min(c0 + COARSE_CHUNK, hi);
+    for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
+        const int64_t c1 = min(c0 + CHUNK, hi);
         const int cb_first = tmp[c0].pad >> shift, cb_last = tmp[c1 - 1].pad >> shift;
         const int b0 = cb_first << shift, span = (cb_last - cb_first + 1) << shift;
         if (span > 1024) {  // rare: one global atomic per record
-            for (int64_t i = c0 + tid; i < c1; i += 1024) {
+            for (int64_t i = c0 + tid; i < c1; i += NT) {
                 const int4 r = *reinterpret_cast<const int4 *>(tmp + i);
                 const int slot = bin_start[r.w] + atomicAdd(&cursor[r.w], 1);
                 *reinterpret_cast<int4 *>(recs + slot) = r;
             }
             continue;
         }
-        hist[tid] = 0;
+        for (int i = tid; i < span; i += NT) hist[i] = 0;
         __syncthreads();
         int4 r[PER];
         int rank[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const int64_t i = c0 + q * 1024 + tid;
+            const int64_t i = c0 + q * NT + tid;
             r[q] = make_int4(0, 0, 0, -1);
-            if (i < c1) r[q] = *reinterpret_cast<const int4 *>(tmp + i);
+            if (i < c1) r[q] = NT == 512 ? ld_nt(reinterpret_cast<const int4 *>(tmp + i)) : *reinterpret_cast<const int4 *>(tmp + i);
         }
 #pragma unroll
         for (int q = 0; q < PER; ++q) rank[q] = r[q].w >= 0 ? atomicAdd(&hist[r[q].w - b0], 1) : 0;
         __syncthreads();
-        {
-            const int c = hist[tid];
-            int incl = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) wtot[wave] = incl;
-            __syncthreads();
-            int base = incl - c;
-            for (int w = 0; w < wave; ++w) base += wtot[w];
-            hist[tid] = base;
-            if (c) gbase[tid] = bin_start[b0 + tid] + atomicAdd(&cursor[b0 + tid], c) - base;
-        }
+        scan_entries<NT>(hist, span, wtot, [&](int e, int c, int base) {
+            gbase[e] = bin_start[b0 + e] + atomicAdd(&cursor[b0 + e], c) - base;
+        });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; ++q)
             if (r[q].w >= 0) *reinterpret_cast<int4 *>(sorted + hist[r[q].w - b0] + rank[q]) = r[q];
         __syncthreads();
         const int total = (int)(c1 - c0);
-        for (int i = tid; i < total; i += 1024) {
+        for (int i = tid; i < total; i += NT) {
             const int4 x = *reinterpret_cast<const int4 *>(sorted + i);
-            *reinterpret_cast<int4 *>(recs + gbase[x.w - b0] + i) = x;
+            int4 *dst = reinterpret_cast<int4 *>(recs + gbase[x.w - b0] + i);
+            if (NT == 512)
+                st_nt(dst, x);
+            else
+                *dst = x;
         }
         __syncthreads();
     }
@@ -409,19 +518,27 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     Tables t = tables_of(ctx, g);
     int32_t *block_hist = nullptr;
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.bin_count, 0, (size_t)g.nbins * sizeof(int32_t), ctx->stream));
+    if (!ctx->pre_light) {
+        ctx->bin_scalars = ctx->d_scalars;
+        ctx->main_binned = true;  // (a later pipelined pre-pass shares recs_tmp / blockhist with this one)
+    }
+    t.scalars = ctx->bin_scalars;  // [0] = dropped (wbin out of range)
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars, 0, 16 * sizeof(int32_t), ctx->stream));
 
     // The histogram of one launch lives in LDS; when there are more bins than fit (large grids x 8
     // w-groups) the bins are covered in several windows, each a full sweep of the stream.  Beyond 8
     // windows the re-reads cost more than plain global atomics.
-    const int cap = (int)(((size_t)ctx->max_lds - 8192) / sizeof(int32_t));
+    // `light`: this pre-pass runs beside a tile kernel (async_prepass): 512-thread work-groups with at most
+    // 40 KB of LDS, whatever that costs in extra sweeps - it has the tile kernel's whole duration.
+    const bool light = ctx->pre_light;
+    const int cap = light ? 10240 : (int)(((size_t)ctx->max_lds - 8192) / sizeof(int32_t));
     const int windows = (g.nbins + cap - 1) / cap;
-    const bool lds_hist = windows <= 8;
+    const bool lds_hist = (windows <= 8 || light) && ctx->opt.prepass != 3;  // prepass = 3: global atomics, no LDS
     const int win = lds_hist ? (g.nbins + windows - 1) / windows : g.nbins;
     const size_t hist_bytes = (size_t)win * sizeof(int32_t);
-    const int threads = 1024;
+    const int threads = light ? 512 : ctx->opt.prepass == 3 ? 256 : 1024;
     // one block per CU with an LDS histogram; more, smaller slices when counting in global memory
-    int blocks = lds_hist ? ctx->num_cu * (hist_bytes <= 64 * 1024 ? 2 : 1) : ctx->num_cu * 8;
+    int blocks = lds_hist ? ctx->num_cu * (hist_bytes <= 64 * 1024 && !light ? 2 : 1) : ctx->num_cu * 8;
     // at least 16 K visibilities per work-group: below that the per-work-group histogram traffic
     // (and the serial walk over work-groups in bin_offsets_kernel) outweighs the parallelism
     int64_t need = (n + 16383) / 16384;
@@ -432,40 +549,61 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     int shift = 6;
     while (((g.nbins + (1 << shift) - 1) >> shift) > 1024) ++shift;
     const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
-    const bool two_level = lds_hist && (ctx->opt.prepass == 2 || (ctx->opt.prepass == 0 && n >= ((int64_t)1 << 22)));
+    const bool two_level =
+        lds_hist && (light || ctx->opt.prepass == 2 || (ctx->opt.prepass == 0 && n >= ((int64_t)1 << 22)));
     if (two_level) {
-        GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)n * sizeof(VisRec)));
+        GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));
         int32_t *ccur = (int32_t *)ctx->blockhist.ptr;
         VisRec *tmp = (VisRec *)ctx->recs_tmp.ptr;
         if (!(ctx->attr_mask & 2u)) {
             GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse_scatter_kernel,
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse_scatter_kernel<1024, 4096>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine_scatter_kernel,
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine_scatter_kernel<1024, 4096>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
             ctx->attr_mask |= 2u;
         }
         GH_CHECK_HIP(ctx, hipMemsetAsync(ccur, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
-        for (int wdw = 0; wdw < windows; ++wdw) {
-            const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
-            hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
-                               v, uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi);
-        }
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
-                           t.work_start, t.cursor);
-        const size_t coarse_lds = (size_t)COARSE_CHUNK * sizeof(VisRec) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
+        const int chunk = light ? 2048 : 4096;
+        const size_t coarse_lds = (size_t)chunk * sizeof(VisRec) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
+        const size_t fine_lds = (size_t)chunk * sizeof(VisRec) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
         int cblocks = ctx->num_cu * 2;
-        int64_t cneed = (n + 4 * COARSE_CHUNK - 1) / (4 * COARSE_CHUNK);
+        int64_t cneed = (n + 4 * chunk - 1) / (4 * chunk);
         if (cblocks > cneed) cblocks = (int)(cneed < 1 ? 1 : cneed);
-        hipLaunchKernelGGL(coarse_scatter_kernel, dim3(cblocks), dim3(1024), coarse_lds, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp);
-        const size_t fine_lds = (size_t)COARSE_CHUNK * sizeof(VisRec) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
-        int fblocks = ctx->num_cu * 2;
-        if (fblocks > cneed) fblocks = (int)(cneed < 1 ? 1 : cneed);
-        hipLaunchKernelGGL(fine_scatter_kernel, dim3(fblocks), dim3(1024), fine_lds, ctx->stream, g, t.bin_start,
-                           t.cursor, shift, tmp, (VisRec *)ctx->recs.ptr);
+        if (light) {
+            GH_CHECK(ws_reserve(ctx, ctx->recs_raw, (size_t)(n > 0 ? n : 1) * (sizeof(VisRec) + sizeof(int32_t)) + 256));
+            VisRec *raw = (VisRec *)ctx->recs_raw.ptr;
+            int32_t *bins = (int32_t *)(raw + (n > 0 ? n : 1));
+            int sblocks = ctx->num_cu * 2;
+            if (sblocks > need) sblocks = (int)need;
+            hipLaunchKernelGGL(light_records_kernel, dim3(sblocks), dim3(512), 0, ctx->stream, g, n, u, v, uv_stride,
+                               wbin, raw, bins, t.scalars);
+            for (int wdw = 0; wdw < windows; ++wdw) {
+                const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
+                hipLaunchKernelGGL(light_count_kernel, dim3(blocks), dim3(512), hist_bytes, ctx->stream, n, bins,
+                                   t.bin_count, b_lo, b_hi);
+            }
+            hipLaunchKernelGGL(bin_scan_kernel<512>, dim3(1), dim3(512), 0, ctx->stream, g, t.bin_count, t.bin_start,
+                               t.work_start, t.cursor);
+            hipLaunchKernelGGL((coarse_scatter_kernel<512, 2048, true>), dim3(cblocks), dim3(512), coarse_lds,
+                               ctx->stream, g, n, u, v, uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp, raw);
+            hipLaunchKernelGGL((fine_scatter_kernel<512, 2048>), dim3(cblocks), dim3(512), fine_lds, ctx->stream, g,
+                               t.bin_start, t.cursor, shift, tmp, (VisRec *)ctx->recs.ptr);
+        } else {
+            for (int wdw = 0; wdw < windows; ++wdw) {
+                const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
+                hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
+                                   v, uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi);
+            }
+            hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
+                               t.work_start, t.cursor);
+            hipLaunchKernelGGL((coarse_scatter_kernel<1024, 4096>), dim3(cblocks), dim3(1024), coarse_lds, ctx->stream,
+                               g, n, u, v, uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp, (const VisRec *)nullptr);
+            hipLaunchKernelGGL((fine_scatter_kernel<1024, 4096>), dim3(cblocks), dim3(1024), fine_lds, ctx->stream, g,
+                               t.bin_start, t.cursor, shift, tmp, (VisRec *)ctx->recs.ptr);
+        }
         GH_CHECK_HIP(ctx, hipGetLastError());
         return GRIDHIP_OK;
     }
@@ -489,7 +627,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         hipLaunchKernelGGL(bin_count_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
                            uv_stride, wbin, t.bin_count, block_hist, t.scalars, 0, g.nbins);
     }
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
+    hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                        t.work_start, t.cursor);
     if (lds_hist) {
         hipLaunchKernelGGL(bin_offsets_kernel, dim3((g.nbins + 255) / 256), dim3(256), 0, ctx->stream, g.nbins, blocks,

@@ -42,7 +42,7 @@ struct Geom {
 };
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, async_prepass = 0;
 };
 
 struct Workspace {
@@ -63,9 +63,24 @@ struct gridhip_ctx {
     gridhip::Workspace tables;  // bin_count / bin_start / work_start / cursors / scalars
     gridhip::Workspace stage;   // staging for the host-pointer entry points
     gridhip::Workspace sorted;  // sorted-list scratch of the tap-reusing tile kernel (tile_sorted.hip)
+    gridhip::Workspace recs_raw;   // unbinned records + bin numbers of a pre-pass that runs beside a tile kernel (bin.hip)
     gridhip::Workspace recs_tmp;   // coarse-binned records between the two scatter levels of the pre-pass (bin.hip)
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
-    int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=last call's n; 16 ints
+    int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [2]=errors, [4..11] work queues, [32..] profile
+    int32_t *bin_scalars = nullptr;  // where the pre-pass counts (d_scalars, or a pipeline buffer's own 16 ints)
+    bool pre_light = false;  // the pre-pass being launched runs beside a tile kernel (bin.hip)
+    // async_prepass: a call's pre-pass runs on pre_stream into one of two record/table sets while the previous
+    // call's tile kernel (main stream) still reads the other (api.hip)
+    struct PipeBuf {
+        gridhip::Workspace recs, tables;
+        hipEvent_t pre_done = nullptr, tile_done = nullptr;
+        bool used = false;
+    } pipe[2];
+    hipStream_t pre_stream = nullptr;
+    int32_t *pipe_scalars = nullptr;  // 2 x 16 ints
+    int pipe_idx = 0;
+    hipEvent_t pipe_order = nullptr;
+    bool main_binned = false;  // a pre-pass ran on the main stream since the last pipelined call (shared scratch)
     int num_cu = 256;
     int max_lds = 160 * 1024;
     bool timing = false;

@@ -219,6 +219,7 @@ int gridhip_create(int device, gridhip_ctx **out)
         gridhip_destroy(ctx);
         return GRIDHIP_ENOMEM;
     }
+    ctx->bin_scalars = ctx->d_scalars;
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
             gridhip_destroy(ctx);
@@ -232,14 +233,22 @@ int gridhip_destroy(gridhip_ctx *ctx)
 {
     if (!ctx) return GRIDHIP_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
     fft_release(ctx);
-    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp};
+    Workspace *all[] = {&ctx->recs,     &ctx->tables,       &ctx->stage,          &ctx->blockhist,     &ctx->sorted,
+                        &ctx->recs_tmp, &ctx->recs_raw, &ctx->pipe[0].recs, &ctx->pipe[0].tables, &ctx->pipe[1].recs, &ctx->pipe[1].tables};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     for (int i = 0; i < 4; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (auto &pb : ctx->pipe) {
+        if (pb.pre_done) (void)hipEventDestroy(pb.pre_done);
+        if (pb.tile_done) (void)hipEventDestroy(pb.tile_done);
+    }
+    if (ctx->pipe_order) (void)hipEventDestroy(ctx->pipe_order);
+    if (ctx->pipe_scalars) (void)hipFree(ctx->pipe_scalars);
+    if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GRIDHIP_OK;
@@ -283,6 +292,7 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "sort")) return &ctx->opt.sort;
     if (!strcmp(key, "dbg")) return &ctx->opt.dbg;
     if (!strcmp(key, "prepass")) return &ctx->opt.prepass;
+    if (!strcmp(key, "async_prepass")) return &ctx->opt.async_prepass;
     return nullptr;
 }
 
@@ -401,7 +411,8 @@ int gridhip_last_dropped(gridhip_ctx *ctx, int64_t *dropped)
     *dropped = 0;
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     int32_t h = 0;
-    GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_scalars, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    // (a pipelined call's pre-pass ran on the side stream, but its tile kernel on ctx->stream waited for it)
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->bin_scalars, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *dropped = h;
     return GRIDHIP_OK;

@@ -44,7 +44,7 @@ struct SortedItem {
 };
 
 template <int S, bool DEGRID, int ABL = 0>
-__global__ void __launch_bounds__(1024) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
+__global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
                                                                 const int32_t *__restrict__ work_start,
                                                                 const double2 *__restrict__ gcf,

@@ -371,6 +371,53 @@ def test_device_path_is_ordered_with_the_callers_stream(ctx):
     assert abs((s1 - G2.sum()).item()) / G2.abs().sum().item() < 1e-12
 
 
+def test_async_prepass_pipelines_consecutive_calls(ctx, oracle):
+    """Option async_prepass: call i+1's pre-pass runs on a side stream beside call i's tile kernel, with two
+    record sets used alternately.  Eight calls over three different input sets are enqueued back to back
+    (device arrays, no synchronisation), with a degrid and an unpipelined gridding call in between (they share
+    the pre-pass temporaries); every grid must match the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    N, W, Q, S = 384, 16, 4, 15
+    t = lambda a: torch.from_numpy(a).to(dev)
+    sets = []
+    for k, n in enumerate((90000, 140000, 60000)):
+        gcf, u, v, wb, vis = case(500 + k, N, N, W, Q, S, S, n, spread=0.58)
+        ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+        sets.append((t(gcf), t(u), t(v), t(wb), t(vis), ref, gcf, u, v, wb))
+    torch.cuda.synchronize()
+    order = [0, 1, 2, 1, 0, 2, 2, 1]
+    grids, extra = [], {}
+    try:
+        ctx.set_option("sort", 1)
+        ctx.set_option("async_prepass", 2)
+        for i, k in enumerate(order):
+            tg, tu, tv, twb, tvis = sets[k][:5]
+            G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+            ctx.convgrid2(tg, G, (tu, tv, None), twb, tvis)
+            grids.append(G)
+            if i == 2:  # a degrid on the main stream (its own pre-pass) between pipelined calls
+                extra["d"] = ctx.degrid2(tg, t(sets[k][5]), (tu, tv, None), twb)
+            if i == 4:  # and an unpipelined gridding call
+                ctx.set_option("async_prepass", 0)
+                extra["g"] = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+                ctx.convgrid2(tg, extra["g"], (tu, tv, None), twb, tvis)
+                ctx.set_option("async_prepass", 2)
+        torch.cuda.synchronize()
+        errors = ctx.get_option("errors")
+        dropped = ctx.last_dropped()
+    finally:
+        ctx.set_option("sort", 0)
+        ctx.set_option("async_prepass", 0)
+    assert errors == 0 and dropped == 0
+    for G, k in zip(grids, order):
+        assert rel(G.cpu().numpy(), sets[k][5]) < TOL
+    assert rel(extra["g"].cpu().numpy(), sets[order[4]][5]) < TOL
+    k = order[2]
+    dref = oracle.degrid2(sets[k][6], sets[k][5], sets[k][7], sets[k][8], sets[k][9])
+    assert rel(extra["d"].cpu().numpy(), dref) < TOL
+
+
 @pytest.mark.parametrize("N,W,Q,S,n", [(512, 32, 8, 15, 200000), (200, 4, 2, 9, 3000), (128, 2, 2, 6, 4000)])
 def test_plan_bins_once_grids_and_degrids_many_times(ctx, oracle, N, W, Q, S, n):
     """gridhip_plan_*: the records are independent of the visibility and kernel values."""

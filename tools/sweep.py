@@ -39,7 +39,7 @@ gcf = bench.synth_kernels(W, Q, S, dev)
 u, v, wb, vis = bench.synth_vis(n, N, W, S, 0x5EEDC0DE, dev, dist=a.dist)
 G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
 ctx.enable_timing(True)
-keys = ("tile", "block", "chunk", "wgroups", "variant", "sort", "dbg", "prepass")
+keys = ("tile", "block", "chunk", "wgroups", "variant", "sort", "dbg", "prepass", "async_prepass")
 for s in a.sets or [""]:
     for k in keys:
         ctx.set_option(k, 0)
@@ -53,6 +53,15 @@ for s in a.sets or [""]:
             ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
             ts.append(ctx.last_timing())
         t = np.array(ts).min(axis=0)
-        print(f"{s or 'default':45s} total {t[0]:8.2f} ms  prepass {t[1]:7.2f}  kernel {t[2]:8.2f}  -> {n / t[0] / 1e3:8.1f} Mvis/s", flush=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+        e1.record()
+        torch.cuda.synchronize()
+        per = e0.elapsed_time(e1) / 8
+        print(f"{s or 'default':45s} total {t[0]:8.2f} ms  prepass {t[1]:7.2f}  kernel {t[2]:8.2f}  -> {n / t[0] / 1e3:8.1f} Mvis/s"
+              f"   | 8 calls back to back: {per:6.2f} ms each -> {n / per / 1e3:8.1f} Mvis/s", flush=True)
     except Exception as e:
         print(f"{s:45s} FAILED {e}", flush=True)
