@@ -35,11 +35,15 @@ print(f"copy x2 alone: {e0.elapsed_time(e1):.2f} ms")
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0.record(); tile(); t1.record(); torch.cuda.synchronize()
 print(f"tile kernel alone: {t0.elapsed_time(t1):.2f} ms")
-for rep in range(3):
-    t0.record()
-    tile()
-    t1.record()
-    with torch.cuda.stream(s2):
-        e0.record(); b.copy_(a); b.copy_(a); e1.record()
-    torch.cuda.synchronize()
-    print(f"together: tile {t0.elapsed_time(t1):.2f} ms, copy x2 {e0.elapsed_time(e1):.2f} ms, copy ended {t0.elapsed_time(e1):.2f} ms after the tile kernel started")
+for ncopy in (2, 3, 4, 6):
+    for rep in range(2):
+        t0.record()
+        tile()
+        t1.record()
+        with torch.cuda.stream(s2):
+            e0.record()
+            for _ in range(ncopy):
+                b.copy_(a)
+            e1.record()
+        torch.cuda.synchronize()
+        print(f"together: tile {t0.elapsed_time(t1):.2f} ms, copy x{ncopy} ({ncopy * 4.3:.1f} GB moved) {e0.elapsed_time(e1):.2f} ms")
