@@ -326,6 +326,45 @@ __global__ void __launch_bounds__(512) light_count_kernel(int64_t n, const int32
     }
 }
 
+// Coarse-bin counts of every work-group's slice of the stream (the slices of coarse_scatter_kernel), and their
+// conversion into each work-group's first slot per coarse bin.  With these the coarse scatter beside a tile kernel
+// reserves nothing at run time: its reservations would be ~25 M returning atomics on ~500 addresses, and hot-spot
+// atomics in L2 are what a co-resident kernel must not do - 24 M of them slow the tile kernel from 14 to 20 ms,
+// while the same number spread over 34 K addresses, or 17 GB of plain copies, cost it nothing
+// (tools/coresidency_probe.py).
+__global__ void __launch_bounds__(512) light_coarse_count_kernel(int64_t n, const int32_t *__restrict__ bins, int shift,
+                                                                 int ncoarse, int32_t *__restrict__ wcnt)
+{
+    extern __shared__ int32_t hist[];
+    if (LIGHT_PRIO) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
+    for (int i = threadIdx.x; i < ncoarse; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    int64_t lo, hi;
+    block_range(n, &lo, &hi);
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        const int b = __builtin_nontemporal_load(bins + k);
+        if (b >= 0) atomicAdd(&hist[b >> shift], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncoarse; i += blockDim.x) wcnt[(size_t)blockIdx.x * ncoarse + i] = hist[i];
+}
+
+// wcnt[w][c] (count) -> first slot of work-group w inside coarse bin c's region.  One thread per coarse bin.
+__global__ void __launch_bounds__(256) light_coarse_offsets_kernel(int ncoarse, int nwg, int shift,
+                                                                   const int32_t *__restrict__ bin_start,
+                                                                   int32_t *__restrict__ wcnt)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncoarse) return;
+    int run = bin_start[c << shift];
+    for (int w = 0; w < nwg; ++w) {
+        int32_t *p = wcnt + (size_t)w * ncoarse + c;
+        const int cnt = *p;
+        *p = run;
+        run += cnt;
+    }
+}
+
 // ---- two-level scatter ----------------------------------------------------------------------
 // Both levels exist in two sizes: <1024 threads, 4096-record chunks> (64 KB of records in LDS, two work-groups per
 // CU) for a pre-pass that has the chip to itself, and <512, 2048> (37-41 KB of LDS, 64 registers) for one that runs
@@ -378,18 +417,22 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel
                                                             const int64_t *__restrict__ wbin,
                                                             const int32_t *__restrict__ bin_start,
                                                             int32_t *__restrict__ ccur, int shift, int ncoarse,
-                                                            VisRec *__restrict__ tmp, const VisRec *__restrict__ raw)
+                                                            VisRec *__restrict__ tmp, const VisRec *__restrict__ raw,
+                                                            const int32_t *__restrict__ woff)
 {
     extern __shared__ int32_t smem[];
     VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [CHUNK]
     int32_t *hist = smem + CHUNK * 4;                   // [ncoarse]: count, then the coarse bin's first slot in `sorted`
     int32_t *gbase = hist + ncoarse;                    // [ncoarse]: tmp position of sorted[0] if it were in this bin
     int32_t *wtot = gbase + ncoarse;                    // [16] per-wave totals of the scan, [16] = chunk total
+    int32_t *lcur = wtot + 32;                          // [ncoarse] (FROM_RECS): this work-group's next slot per coarse bin
     const int tid = threadIdx.x;
     constexpr int PER = CHUNK / NT;
     if (LIGHT_PRIO && NT == 512) __builtin_amdgcn_s_setprio(LIGHT_PRIO);  // beside a tile kernel: see bin_count_kernel
     int64_t lo, hi;
     block_range(n, &lo, &hi);
+    if (FROM_RECS)
+        for (int i = tid; i < ncoarse; i += NT) lcur[i] = woff[(size_t)blockIdx.x * ncoarse + i];
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         for (int i = tid; i < ncoarse; i += NT) hist[i] = 0;
         __syncthreads();
@@ -415,7 +458,12 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel
         __syncthreads();
         // exclusive scan of the counts and the global reservations
         scan_entries<NT>(hist, ncoarse, wtot, [&](int e, int c, int base) {
-            gbase[e] = bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
+            if (FROM_RECS) {  // slots fixed beforehand (light_coarse_offsets_kernel): no atomics beside a tile kernel
+                const int first = lcur[e];
+                lcur[e] = first + c;
+                gbase[e] = first - base;
+            } else
+                gbase[e] = bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
         });
         __syncthreads();
 #pragma unroll
@@ -447,10 +495,13 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel
 // coarse bins, i.e. at most a few hundred bins.  The chunk is counting-sorted by bin in LDS exactly as level 1 sorts
 // by coarse bin, each bin's range is reserved with one global atomic, and the records leave as runs.  A chunk that
 // spans more than 1024 bins (very sparse regions) falls back to one global atomic per record.
+// `tmp` is ordered by (bin >> in_shift); this level orders by key = bin >> kshift (kshift < in_shift; 0 = the final
+// level), writing key k's records to [bin_start[k << kshift], ...) of `out`, with `cursor` (one entry per key,
+// zeroed) handing out the ranges.
 template <int NT, int CHUNK>
 __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) fine_scatter_kernel(Geom g, const int32_t *__restrict__ bin_start,
-                                                          int32_t *__restrict__ cursor, int shift,
-                                                          const VisRec *__restrict__ tmp, VisRec *__restrict__ recs)
+                                                          int32_t *__restrict__ cursor, int in_shift, int kshift,
+                                                          const VisRec *__restrict__ tmp, VisRec *__restrict__ out)
 {
     extern __shared__ int32_t smem[];
     VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [CHUNK]
@@ -464,15 +515,17 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) fine_scatter_kernel(G
     int64_t per = (ntot + gridDim.x - 1) / gridDim.x;
     per = (per + CHUNK - 1) / CHUNK * CHUNK;
     const int64_t lo = min((int64_t)blockIdx.x * per, ntot), hi = min(lo + per, ntot);
+    const int up = in_shift - kshift;
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         const int64_t c1 = min(c0 + CHUNK, hi);
-        const int cb_first = tmp[c0].pad >> shift, cb_last = tmp[c1 - 1].pad >> shift;
-        const int b0 = cb_first << shift, span = (cb_last - cb_first + 1) << shift;
+        const int cb_first = tmp[c0].pad >> in_shift, cb_last = tmp[c1 - 1].pad >> in_shift;
+        const int k0 = cb_first << up, span = (cb_last - cb_first + 1) << up;  // keys k0 .. k0 + span
         if (span > 1024) {  // rare: one global atomic per record
             for (int64_t i = c0 + tid; i < c1; i += NT) {
                 const int4 r = *reinterpret_cast<const int4 *>(tmp + i);
-                const int slot = bin_start[r.w] + atomicAdd(&cursor[r.w], 1);
-                *reinterpret_cast<int4 *>(recs + slot) = r;
+                const int k = r.w >> kshift;
+                const int slot = bin_start[k << kshift] + atomicAdd(&cursor[k], 1);
+                *reinterpret_cast<int4 *>(out + slot) = r;
             }
             continue;
         }
@@ -487,20 +540,20 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) fine_scatter_kernel(G
             if (i < c1) r[q] = NT == 512 ? ld_nt(reinterpret_cast<const int4 *>(tmp + i)) : *reinterpret_cast<const int4 *>(tmp + i);
         }
 #pragma unroll
-        for (int q = 0; q < PER; ++q) rank[q] = r[q].w >= 0 ? atomicAdd(&hist[r[q].w - b0], 1) : 0;
+        for (int q = 0; q < PER; ++q) rank[q] = r[q].w >= 0 ? atomicAdd(&hist[(r[q].w >> kshift) - k0], 1) : 0;
         __syncthreads();
         scan_entries<NT>(hist, span, wtot, [&](int e, int c, int base) {
-            gbase[e] = bin_start[b0 + e] + atomicAdd(&cursor[b0 + e], c) - base;
+            gbase[e] = bin_start[(k0 + e) << kshift] + atomicAdd(&cursor[k0 + e], c) - base;
         });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-            if (r[q].w >= 0) *reinterpret_cast<int4 *>(sorted + hist[r[q].w - b0] + rank[q]) = r[q];
+            if (r[q].w >= 0) *reinterpret_cast<int4 *>(sorted + hist[(r[q].w >> kshift) - k0] + rank[q]) = r[q];
         __syncthreads();
         const int total = (int)(c1 - c0);
         for (int i = tid; i < total; i += NT) {
             const int4 x = *reinterpret_cast<const int4 *>(sorted + i);
-            int4 *dst = reinterpret_cast<int4 *>(recs + gbase[x.w - b0] + i);
+            int4 *dst = reinterpret_cast<int4 *>(out + gbase[(x.w >> kshift) - k0] + i);
             if (NT == 512)
                 st_nt(dst, x);
             else
@@ -546,14 +599,17 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     if (blocks > need) blocks = (int)need;
 
     // two-level scatter for large streams (only the counting sweep needs the histogram windows)
-    int shift = 6;
+    int shift = light ? 8 : 6;  // beside a tile kernel: fewer, longer runs per level and one level more
     while (((g.nbins + (1 << shift) - 1) >> shift) > 1024) ++shift;
     const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
     const bool two_level =
         lds_hist && (light || ctx->opt.prepass == 2 || (ctx->opt.prepass == 0 && n >= ((int64_t)1 << 22)));
     if (two_level) {
         GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
-        GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));
+        // coarse cursors; beside a tile kernel also every work-group's slots per coarse bin
+        GH_CHECK(ws_reserve(ctx, ctx->blockhist,
+                            ((size_t)(light ? ctx->num_cu * 2 + 1 : 1) * ncoarse + (light ? (size_t)g.nbins + 64 : 0)) *
+                                sizeof(int32_t)));
         int32_t *ccur = (int32_t *)ctx->blockhist.ptr;
         VisRec *tmp = (VisRec *)ctx->recs_tmp.ptr;
         if (!(ctx->attr_mask & 2u)) {
@@ -587,10 +643,33 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             }
             hipLaunchKernelGGL(bin_scan_kernel<512>, dim3(1), dim3(512), 0, ctx->stream, g, t.bin_count, t.bin_start,
                                t.work_start, t.cursor);
-            hipLaunchKernelGGL((coarse_scatter_kernel<512, 2048, true>), dim3(cblocks), dim3(512), coarse_lds,
-                               ctx->stream, g, n, u, v, uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp, raw);
-            hipLaunchKernelGGL((fine_scatter_kernel<512, 2048>), dim3(cblocks), dim3(512), fine_lds, ctx->stream, g,
-                               t.bin_start, t.cursor, shift, tmp, (VisRec *)ctx->recs.ptr);
+            // every work-group's slots per coarse bin, fixed beforehand (no reservations at run time)
+            int32_t *woff = (int32_t *)ctx->blockhist.ptr + ncoarse;
+            hipLaunchKernelGGL(light_coarse_count_kernel, dim3(cblocks), dim3(512), (size_t)ncoarse * sizeof(int32_t),
+                               ctx->stream, n, bins, shift, ncoarse, woff);
+            hipLaunchKernelGGL(light_coarse_offsets_kernel, dim3((ncoarse + 255) / 256), dim3(256), 0, ctx->stream,
+                               ncoarse, cblocks, shift, t.bin_start, woff);
+            hipLaunchKernelGGL((coarse_scatter_kernel<512, 2048, true>), dim3(cblocks), dim3(512),
+                               coarse_lds + (size_t)ncoarse * sizeof(int32_t), ctx->stream, g, n, u, v, uv_stride, wbin,
+                               t.bin_start, ccur, shift, ncoarse, tmp, raw, woff);
+            // runs shorter than 128 B are what slows a tile kernel next door (tools/coresidency_probe.py), so the
+            // levels below the coarse one go in steps of 16 keys: with 2 048-record chunks every run is >= 1 KB
+            const VisRec *src = tmp;
+            VisRec *spare = raw;  // (its records have been consumed by the coarse level)
+            for (int in_shift = shift; in_shift > 0;) {
+                const int kshift = in_shift > 4 ? in_shift - 4 : 0;
+                VisRec *dst = kshift == 0 ? (VisRec *)ctx->recs.ptr : spare;
+                int32_t *cur = t.cursor;
+                if (kshift > 0) {  // cursors of an intermediate level: behind the work-group offsets
+                    cur = (int32_t *)ctx->blockhist.ptr + (size_t)(ctx->num_cu * 2 + 1) * ncoarse;
+                    GH_CHECK_HIP(ctx, hipMemsetAsync(cur, 0, (size_t)((g.nbins >> kshift) + 1) * sizeof(int32_t), ctx->stream));
+                }
+                hipLaunchKernelGGL((fine_scatter_kernel<512, 2048>), dim3(cblocks), dim3(512), fine_lds, ctx->stream, g,
+                                   t.bin_start, cur, in_shift, kshift, src, dst);
+                spare = const_cast<VisRec *>(src);
+                src = dst;
+                in_shift = kshift;
+            }
         } else {
             for (int wdw = 0; wdw < windows; ++wdw) {
                 const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
@@ -600,9 +679,10 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                                t.work_start, t.cursor);
             hipLaunchKernelGGL((coarse_scatter_kernel<1024, 4096>), dim3(cblocks), dim3(1024), coarse_lds, ctx->stream,
-                               g, n, u, v, uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp, (const VisRec *)nullptr);
+                               g, n, u, v, uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp, (const VisRec *)nullptr,
+                               (const int32_t *)nullptr);
             hipLaunchKernelGGL((fine_scatter_kernel<1024, 4096>), dim3(cblocks), dim3(1024), fine_lds, ctx->stream, g,
-                               t.bin_start, t.cursor, shift, tmp, (VisRec *)ctx->recs.ptr);
+                               t.bin_start, t.cursor, shift, 0, tmp, (VisRec *)ctx->recs.ptr);
         }
         GH_CHECK_HIP(ctx, hipGetLastError());
         return GRIDHIP_OK;
