@@ -184,8 +184,8 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                 }
                 const int pos = atomicAdd(&hist[key], 1);
                 if ((unsigned)pos < (unsigned)batch) {
-                    smo[pos] = make_uint2(((uint32_t)key << 16) | (uint32_t)((rec[q].lxy >> 16) << 8) |
-                                              (uint32_t)(rec[q].lxy & 0xff),
+                    // meta = slice key | the footprint origin's cell offset in the tile (< 8192: sorted_plan)
+                    smo[pos] = make_uint2(((uint32_t)key << 16) | (uint32_t)((rec[q].lxy >> 16) * g.ldw + (rec[q].lxy & 0xffff)),
                                           (uint32_t)rec[q].orig);
                     if (!DEGRID) svals[pos] = val[q];
                 } else
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                     for (int i = 0; i < len; ++i) {
                         const int j = start + i;
                         const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
-                        const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+                        const int lbase = (int)(m & 0xffff);
                         const double vx = readlane_f64(vB.x, j), vy = readlane_f64(vB.y, j);
 #pragma unroll
                         for (int s = 0; s < NSTEP; ++s) {
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                             if (i + q < len) {  // uniform
                                 const int j = start + i + q;
                                 const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
-                                const int lbase = (int)((m >> 8) & 0xff) * g.ldw + (int)(m & 0xff);
+                                const int lbase = (int)(m & 0xffff);
                                 oo[q] = __builtin_amdgcn_readlane((int)mo.y, j);
 #pragma unroll
                                 for (int s = 0; s < NSTEP; ++s) {
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             // equals bcnt here), so LLVM cannot sink them below the exit test, and nothing waits for them.
             if (done > bcnt) asm volatile("" ::"v"(kA[0].x), "v"(kA[NSTEP - 1].y), "v"(kB[0].x), "v"(kB[NSTEP - 1].y));
             if (EXTRA > 0 && !(ABL & 1) && lane < bcnt) {
-                const int lb = (int)((mo.x >> 8) & 0xff) * g.ldw + (int)(mo.x & 0xff);
+                const int lb = (int)(mo.x & 0xffff);
 #pragma unroll
                 for (int e = 0; e < EXTRA; ++e) {
                     const int t = S2 - EXTRA + e;
