@@ -47,8 +47,9 @@ def lds_atomic_cycles_per_vis(S):
     taps = S * S
     full, tail = divmod(taps, 64)
     cyc = full * 2 * 8
-    if 32 < tail <= 34:  # the last step keeps 32 taps; the others go once per block of 64 records
-        cyc += 2 * 6 + (tail - 32) * 2 * 8 / 64
+    if 32 < tail <= 34:  # the last step keeps 32 taps and serves two visibilities of a run at once (a lone one
+        # pays 2 x 6 cycles for it); the other taps go once per block of 64 records
+        cyc += 2 * 8 / 2 + (tail - 32) * 2 * 8 / 64
     elif tail:
         cyc += 2 * (6 if tail <= 32 else 7 if tail <= 48 else 8)
     return cyc

@@ -63,6 +63,9 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
     // its own record (gridding only; 15x15: 62 -> 60.25 LDS cycles per visibility).
     constexpr int EXTRA = (!DEGRID && TAIL0 > 32 && TAIL0 <= 34) ? TAIL0 - 32 : 0;
     constexpr int TAIL = TAIL0 - EXTRA;
+    // With a 32-tap last step, two visibilities of a run share it: lanes 32..63 hold the same 32 taps again and
+    // take the second visibility (one full-width instruction pair, 16 cycles, instead of two half-width ones, 24).
+    constexpr bool PAIR = !DEGRID && TAIL == 32;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int plane = g.lrows * g.ldw;
@@ -213,10 +216,10 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
         int t = s * 64 + lane;
-        if (s == NSTEP - 1 && !tail_ok) t = 0;  // idle lanes of the last step (switched off there)
+        if (s == NSTEP - 1 && !tail_ok) t = PAIR ? s * 64 + lane - 32 : 0;  // idle lanes (PAIR: the same taps again)
         loff[s] = (t / S) * g.ldw + (t % S);
     }
-    const int ttail = tail_ok ? (NSTEP - 1) * 64 + lane : 0;
+    const int ttail = tail_ok ? (NSTEP - 1) * 64 + lane : PAIR ? (NSTEP - 1) * 64 + lane - 32 : 0;
 
     // ---- a walker's job: its piece of the sorted list of scratch half `slot` ------------------------------
     // The piece is taken in blocks of 64 records: two coalesced loads bring a block into registers, one
@@ -278,7 +281,56 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             };
             auto process = [&](const double2(&k)[NSTEP], int start, int len) {
                 if (!DEGRID) {
-                    for (int i = 0; i < len; ++i) {
+                    int i = 0;
+                    if (PAIR) {
+                        for (; i + 1 < len; i += 2) {
+                            const int j0 = start + i, j1 = j0 + 1;
+                            const int lb0 = (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, j0) & 0xffff);
+                            const int lb1 = (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, j1) & 0xffff);
+                            const double vx0 = readlane_f64(vB.x, j0), vy0 = readlane_f64(vB.y, j0);
+                            const double vx1 = readlane_f64(vB.x, j1), vy1 = readlane_f64(vB.y, j1);
+#pragma unroll
+                            for (int s = 0; s < NSTEP - 1; ++s) {
+                                double *cell = lre + (lb0 + loff[s]);
+                                if (ABL & 1) continue;
+                                __hip_atomic_fetch_add(cell, vx0 * k[s].x - vy0 * k[s].y, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, vx0 * k[s].y + vy0 * k[s].x,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+#pragma unroll
+                            for (int s = 0; s < NSTEP - 1; ++s) {
+                                double *cell = lre + (lb1 + loff[s]);
+                                if (ABL & 1) continue;
+                                __hip_atomic_fetch_add(cell, vx1 * k[s].x - vy1 * k[s].y, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, vx1 * k[s].y + vy1 * k[s].x,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            // the shared last step: each half computes its own visibility's products (EXEC-masked
+                            // branches: the empty asm keeps them branches), then all 64 lanes add
+                            const double2 kl = k[NSTEP - 1];
+                            double re, im;
+                            int a;
+                            if (lane < 32) {
+                                re = vx0 * kl.x - vy0 * kl.y;
+                                im = vx0 * kl.y + vy0 * kl.x;
+                                a = lb0 + loff[NSTEP - 1];
+                                asm volatile("" : "+v"(a));
+                            } else {
+                                re = vx1 * kl.x - vy1 * kl.y;
+                                im = vx1 * kl.y + vy1 * kl.x;
+                                a = lb1 + loff[NSTEP - 1];
+                                asm volatile("" : "+v"(a));
+                            }
+                            if (!(ABL & 1)) {
+                                __hip_atomic_fetch_add(lre + a, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(lre + a + SORTED_IM_OFF / 8, im, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                    for (; i < len; ++i) {
                         const int j = start + i;
                         const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
                         const int lbase = (int)(m & 0xffff);
