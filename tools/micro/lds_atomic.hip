@@ -1,6 +1,7 @@
 // Micro-benchmark: LDS fp64 atomic-add issue cost per 64-lane instruction on gfx950, by active-lane
 // pattern and against plain read / write of the same shape.  One work-group per CU, all waves looping.
-// usage: lds_atomic [waves_per_wg]
+// build: hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -o tools/micro/lds_atomic tools/micro/lds_atomic.hip
+// usage: tools/micro/lds_atomic   (results: profiles/r01_lds_atomic_microbench.txt)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
