@@ -151,6 +151,8 @@ __global__ void __launch_bounds__(256) aw_vis_rows_kernel(int64_t H, int64_t Wd,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v4 = lane >> 4, x = lane & 15;
     double2 *bp = sm + (size_t)(wave * 4 + v4) * S * PW;  // this visibility's padded w-kernel slice
+    // pair-kernel rows pass through a two-deep LDS ring (one element per lane and row, fetched one row ahead)
+    double2 *aring = sm + (size_t)16 * S * PW + (size_t)wave * 2 * 64;
     const int64_t groups = (n + 3) / 4;
     for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
         const int64_t k = grp * 4 + v4;
@@ -202,16 +204,16 @@ __global__ void __launch_bounds__(256) aw_vis_rows_kernel(int64_t H, int64_t Wd,
         for (int r = 0; r < S; ++r) acc[r] = make_double2(0.0, 0.0);
         double2 *out = kperv + (size_t)(have ? k : 0) * S2 + (size_t)x * S;  // out[x * S + y]: comes out transposed
         const bool store = have && x < S;
-        double2 arow[S], anext[S], b0[S], b1[S];  // b0 / b1: w-kernel row r for even / odd r, one fetched ahead
-#pragma unroll
-        for (int j = 0; j < S; ++j) anext[j] = pk[j];
+        double2 arow[S], b0[S], b1[S];  // b0 / b1: w-kernel row r for even / odd r, one fetched ahead
+        const int xa = x < S ? x : S - 1;
+        double2 anext = pk[xa];  // this lane's element of row 0
         for (int i = 0; i < S; ++i) {
+            aring[(i & 1) * 64 + lane] = anext;
+            if (i + 1 < S) anext = pk[(i + 1) * S + xa];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < S; ++j) arow[j] = anext[j];
-            if (i + 1 < S) {
-#pragma unroll
-                for (int j = 0; j < S; ++j) anext[j] = pk[(i + 1) * S + j];
-            }
+            for (int j = 0; j < S; ++j) arow[j] = aring[(i & 1) * 64 + v4 * 16 + j];  // a[i][j] of this lane's visibility
             const int rlo = max(0, C - i), rhi = min(S - 1, S - 1 + C - i);  // rows r whose y = r + i - C exists
             {
                 const double2 *brow = bp + rlo * PW + (x + 2 * C);  // b[r][x + C - j] = brow[-j]
@@ -330,7 +332,7 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         const int64_t m = n - lo < batch ? n - lo : batch;
         if (S == 15) {
             constexpr int S_ = 15;
-            const size_t rows_lds = (size_t)16 * S_ * (S_ + 2 * (S_ / 2)) * sizeof(double2);  // 16 padded slices
+            const size_t rows_lds = ((size_t)16 * S_ * (S_ + 2 * (S_ / 2)) + 4 * 2 * 64) * sizeof(double2);  // 16 padded slices + row rings
             if (!(ctx->attr_mask & 4u)) {
                 AW_HIP(hipFuncSetAttribute((const void *)aw_vis_rows_kernel<S_>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
