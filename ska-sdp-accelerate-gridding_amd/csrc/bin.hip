@@ -11,7 +11,7 @@
 // 2 = two levels).  A record written straight to its bin is a lone 16-byte store into one of ~10^5
 // open regions, i.e. one partial-line HBM write per visibility, which is what bounds the one-level
 // sweep (2.6 ms for 10^8 records against 0.45 ms for the counting sweep over the same input).
-//   coarse_scatter : chunks of 4096 visibilities are counting-sorted by COARSE bin (2^k consecutive
+//   coarse_scatter : chunks of 8192 visibilities are counting-sorted by COARSE bin (2^k consecutive
 //                    bins) in LDS and written as runs into a temporary array laid out like the final
 //                    one at coarse granularity
 //   fine_scatter   : segments of the temporary array (a handful of coarse bins each, so few open
@@ -366,8 +366,8 @@ __global__ void __launch_bounds__(256) light_coarse_offsets_kernel(int ncoarse, 
 }
 
 // ---- two-level scatter ----------------------------------------------------------------------
-// Both levels exist in two sizes: <1024 threads, 4096-record chunks> (64 KB of records in LDS, two work-groups per
-// CU) for a pre-pass that has the chip to itself, and <512, 2048> (37-41 KB of LDS, 64 registers) for one that runs
+// Both levels exist in two sizes: <1024 threads, 8192-record chunks> (128 KB of records in LDS, one work-group per
+// CU; 4096-record chunks at two per CU measured 0.1 ms slower) for a pre-pass that has the chip to itself, and <512, 2048> (37-41 KB of LDS, 64 registers) for one that runs
 // on a side stream BESIDE the previous call's tile kernel, whose persistent work-groups leave 44 KB of LDS, half
 // the wave slots and a quarter of the registers of every CU free (option "async_prepass").
 
@@ -615,17 +615,17 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         if (!(ctx->attr_mask & 2u)) {
             GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse_scatter_kernel<1024, 4096>,
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse_scatter_kernel<1024, 8192>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine_scatter_kernel<1024, 4096>,
+            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine_scatter_kernel<1024, 8192>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
             ctx->attr_mask |= 2u;
         }
         GH_CHECK_HIP(ctx, hipMemsetAsync(ccur, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
-        const int chunk = light ? 2048 : 4096;
+        const int chunk = light ? 2048 : 8192;
         const size_t coarse_lds = (size_t)chunk * sizeof(VisRec) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
         const size_t fine_lds = (size_t)chunk * sizeof(VisRec) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
-        int cblocks = ctx->num_cu * 2;
+        int cblocks = light ? ctx->num_cu * 2 : ctx->num_cu;  // (8192-record chunks: one work-group per CU)
         int64_t cneed = (n + 4 * chunk - 1) / (4 * chunk);
         if (cblocks > cneed) cblocks = (int)(cneed < 1 ? 1 : cneed);
         if (light) {
@@ -678,10 +678,10 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             }
             hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                                t.work_start, t.cursor);
-            hipLaunchKernelGGL((coarse_scatter_kernel<1024, 4096>), dim3(cblocks), dim3(1024), coarse_lds, ctx->stream,
+            hipLaunchKernelGGL((coarse_scatter_kernel<1024, 8192>), dim3(cblocks), dim3(1024), coarse_lds, ctx->stream,
                                g, n, u, v, uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp, (const VisRec *)nullptr,
                                (const int32_t *)nullptr);
-            hipLaunchKernelGGL((fine_scatter_kernel<1024, 4096>), dim3(cblocks), dim3(1024), fine_lds, ctx->stream, g,
+            hipLaunchKernelGGL((fine_scatter_kernel<1024, 8192>), dim3(cblocks), dim3(1024), fine_lds, ctx->stream, g,
                                t.bin_start, t.cursor, shift, 0, tmp, (VisRec *)ctx->recs.ptr);
         }
         GH_CHECK_HIP(ctx, hipGetLastError());
