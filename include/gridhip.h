@@ -76,7 +76,8 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *   "sort"      order each work item's records by kernel slice so that runs of visibilities
  *               reuse their taps from registers: 0 = auto, 1 = on (when the shape allows), 2 = off
  *   "prepass"   scatter of the binning pre-pass: 0 = auto (two levels from 2^22 visibilities), 1 = one level,
- *               2 = two levels (LDS-sorted runs into coarse bins, then into the bins)
+ *               2 = two levels (LDS-sorted runs into coarse bins, then into the bins), 3 = one level with global
+ *               atomics only (no LDS; a measured baseline: 16 ms against 2.1 ms at 10^8 visibilities)
  *   "async_prepass"  1 = the coordinate arrays (u, v, wbin) given to gridhip_convgrid2_dev are complete when the
  *               call is made (not the product of work still queued on the stream): the binning pre-pass of a call
  *               then runs on an internal stream beside the previous call's tile kernel (two record sets

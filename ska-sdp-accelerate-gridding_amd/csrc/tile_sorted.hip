@@ -583,7 +583,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
         GH_CHECK_HIP(ctx, hipGetLastError());                                                                    \
         return GRIDHIP_OK;                                                                                       \
     }
-    GH_ABL(1) GH_ABL(2) GH_ABL(3) GH_ABL(4) GH_ABL(5) GH_ABL(7) GH_ABL(8) GH_ABL(15) GH_ABL(16) GH_ABL(48)
+    GH_ABL(1) GH_ABL(2) GH_ABL(3) GH_ABL(4) GH_ABL(5) GH_ABL(7) GH_ABL(8) GH_ABL(15) GH_ABL(16)
 #undef GH_ABL
     switch (g.gh) {
         GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)
