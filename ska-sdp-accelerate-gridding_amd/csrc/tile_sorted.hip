@@ -39,6 +39,10 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // store) disappear behind it.  A work-group of one wave does both, one after the other.
 constexpr int SORTED_IM_OFF = 65528;  // largest multiple of 8 that a DS instruction's offset field holds
 
+// piece boundaries of the 15 walkers in 1/1024ths of the sorted list: weights 1.50 (walkers 0..3), 1.10 (4..7),
+// 0.74 (8..11), 0.55 (12..14) of an equal share (three rounds of weight / measured finishing time)
+__device__ const int cut15[16] = {0, 103, 205, 308, 410, 485, 560, 635, 710, 760, 811, 861, 911, 949, 986, 1024};
+
 struct SortedItem {
     int32_t valid, tile, grp, staged;
 };
@@ -228,7 +232,17 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
     auto walk = [&](int slot, int staged, int first_slice) {
         const double2 *svals = svals_wg + (size_t)slot * batch;
         const uint2 *smo = smo_wg + (size_t)slot * batch;
-        const int seg_lo = (int)(((int64_t)staged * wave) / nwalk), seg_hi = (int)(((int64_t)staged * (wave + 1)) / nwalk);
+        // With 15 walkers the pieces are weighted: the SIMD arbiter favours its oldest wave, so with equal pieces
+        // walkers 0..3 finish at 0.55 of the walk and the last three run on for the rest with the LDS unit half idle.
+        // cut[w] / 1024 = share of the list in front of walker w (option dbg = 256: equal pieces, for comparison).
+        int seg_lo, seg_hi;
+        if (nwalk == 15 && !(g.dbg & 256)) {
+            seg_lo = (int)(((int64_t)staged * cut15[wave]) >> 10);
+            seg_hi = (int)(((int64_t)staged * cut15[wave + 1]) >> 10);
+        } else {
+            seg_lo = (int)(((int64_t)staged * wave) / nwalk);
+            seg_hi = (int)(((int64_t)staged * (wave + 1)) / nwalk);
+        }
         if (seg_lo >= seg_hi) return;
         auto load_block = [&](int b0, uint2 &mo, double2 &v) {
             const int idx = max(min(b0 + lane, seg_hi - 1), seg_lo);  // past the end: the piece's last record
