@@ -41,7 +41,7 @@ constexpr int SORTED_IM_OFF = 65528;  // largest multiple of 8 that a DS instruc
 
 // piece boundaries of the 15 walkers in 1/1024ths of the sorted list: weights 1.50 (walkers 0..3), 1.10 (4..7),
 // 0.74 (8..11), 0.55 (12..14) of an equal share (three rounds of weight / measured finishing time)
-__device__ const int cut15[16] = {0, 103, 205, 308, 410, 485, 560, 635, 710, 760, 811, 861, 911, 949, 986, 1024};
+__device__ const int cut15[16] = {0, 105, 210, 314, 419, 496, 572, 649, 726, 774, 823, 872, 920, 955, 989, 1024};
 
 struct SortedItem {
     int32_t valid, tile, grp, staged;
