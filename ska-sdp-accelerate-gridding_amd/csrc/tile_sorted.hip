@@ -545,7 +545,7 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     const size_t hist = (size_t)((keys + 1 + 3) & ~3) * 4;
     if (tile + hist + 128 > (size_t)ctx->max_lds) return false;
     (void)block;
-    int c = ctx->opt.chunk ? (int)ctx->opt.chunk : 8192;
+    int c = ctx->opt.chunk ? (int)ctx->opt.chunk : 16384;  // (dense bins: 16384 measured 1.4 % faster than 8192)
     c = c < 64 ? 64 : c > 16384 ? 16384 : c;
     *nkeys = (int)keys;
     *batch = c;
