@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             mo = smo[idx];
             if (!DEGRID) v = svals[idx];
         };
-        auto issue = [&](double2(&k)[NSTEP], int key) {
+        auto issue = [&](double2(&k)[NSTEP], int key, int len) {
             key = min(max(key, 0), nkeys - 1);  // never form an address outside the kernel table
             asm volatile("" : "+s"(key));       // (an empty run repeats a key: keep its loads loads, not copies)
             const double2 *kp = gcf + (size_t)(first_slice + key) * S2;
@@ -258,9 +258,12 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                 for (int s = 0; s < NSTEP; ++s) k[s] = make_double2((double)key, (double)(lane + s));
                 return;
             }
+            // the runs of length 0 that pad a block's tail keep the instruction count (and the vmcnt arithmetic)
+            // but fetch one element for the whole wave
+            const int lofs = len > 0 ? lane : 0, lt = len > 0 ? ttail : 0;
 #pragma unroll
-            for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lane];
-            k[NSTEP - 1] = kp[ttail];
+            for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lofs];
+            k[NSTEP - 1] = kp[lt];
         };
         uint2 moN;
         double2 vN = make_double2(0.0, 0.0);
@@ -412,13 +415,13 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             double2 kA[NSTEP], kB[NSTEP], kC[NSTEP];
             int keyA, startA, lenA, keyB, startB, lenB, keyC, startC, lenC;
             advance(keyA, startA, lenA);
-            issue(kA, keyA);
+            issue(kA, keyA, lenA);
             advance(keyB, startB, lenB);
-            issue(kB, keyB);
+            issue(kB, keyB, lenB);
             int done = 0;
             for (;;) {
                 advance(keyC, startC, lenC);
-                issue(kC, keyC);
+                issue(kC, keyC, lenC);
                 asm volatile("" ::: "memory");  // compiler fence: the prefetch may not sink below this point
                 __builtin_amdgcn_sched_barrier(0);
                 process(kA, startA, lenA);
@@ -426,7 +429,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                 done += lenA;
 
                 advance(keyA, startA, lenA);
-                issue(kA, keyA);
+                issue(kA, keyA, lenA);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 process(kB, startB, lenB);
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                 done += lenB;
 
                 advance(keyB, startB, lenB);
-                issue(kB, keyB);
+                issue(kB, keyB, lenB);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 process(kC, startC, lenC);
