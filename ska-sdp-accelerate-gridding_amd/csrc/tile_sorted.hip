@@ -87,6 +87,9 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
 
     const bool solo = nw == 1;
     const bool is_sorter = wave == nw - 1;
+    // the sorter is the youngest wave of its SIMD, i.e. last at the arbiter, and its work is a chain of latencies:
+    // it goes first instead (it issues few instructions)
+    if (is_sorter && !solo && !(g.dbg & 512)) __builtin_amdgcn_s_setprio(3);
     const bool is_walker = solo || !is_sorter;
     const int nwalk = solo ? 1 : nw - 1;
     const int ncell = g.lrows * g.lcols;
