@@ -39,9 +39,9 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // store) disappear behind it.  A work-group of one wave does both, one after the other.
 constexpr int SORTED_IM_OFF = 65528;  // largest multiple of 8 that a DS instruction's offset field holds
 
-// piece boundaries of the 15 walkers in 1/1024ths of the sorted list: weights 1.50 (walkers 0..3), 1.10 (4..7),
-// 0.74 (8..11), 0.55 (12..14) of an equal share (three rounds of weight / measured finishing time)
-__device__ const int cut15[16] = {0, 105, 210, 314, 419, 496, 572, 649, 726, 774, 823, 872, 920, 955, 989, 1024};
+// piece boundaries of the 15 walkers in 1/1024ths of the sorted list: weights 1.55 (walkers 0..3), 1.14 (4..7),
+// 0.71 (8..11), 0.48 (12..14) of an equal share (five rounds of weight / measured finishing time: all within 6 %)
+__device__ const int cut15[16] = {0, 106, 211, 317, 422, 500, 578, 655, 733, 781, 829, 877, 926, 958, 991, 1024};
 
 struct SortedItem {
     int32_t valid, tile, grp, staged;
