@@ -1,49 +1,123 @@
 #!/usr/bin/env python3
 """bench.py — Mvis/s of the w-projection gridder (convgrid2 semantics) on MI355X.
 
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`),
-visibilities sharded across ranks (weak scaling: every rank grids its own `--nvis` shard onto a
-private N x N complex128 grid), one RCCL fp64 all-reduce of the partial grids per step.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5]
 
-A "step" = binning pre-pass + tile kernel over the rank's whole shard (+ all-reduce when N > 1),
+One process per GPU.  Started under `python -m torch.distributed.run --nproc-per-node N` the ranks come from
+the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); started as a plain command with --gpus N > 1 this
+process only spawns the N rank processes (before anything touches a GPU) and relays rank 0's JSON line.
+Visibilities are sharded across ranks (weak scaling: every rank grids its own shard onto a private N x N
+complex128 grid) and the partial grids are summed with ONE RCCL fp64 all-reduce per step, issued on a side
+stream so that it overlaps the next step's gridding.
+
+A "step" = binning pre-pass + tile kernel over the rank's whole shard (+ grid clear and all-reduce when N > 1),
 inputs already resident in HBM.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
-  10^8 synthetic visibilities, 4096^2 grid, 128 w-planes, 15x15 support, oversampling Q = 8,
-  uniform uv distribution (SURVEY.md §8d distribution A).
-`--workload cfg2` selects configs[1] (10^6 vis, 2048^2, 7x7).
+Workloads (BASELINE.json configs):
+  cfg3 (default; configs[2], the configuration the metric is quoted on): 10^8 synthetic visibilities, 4096^2 grid,
+       128 w-planes, 15x15 support, oversampling Q = 8, uniform uv distribution (SURVEY.md §8d distribution A)
+  cfg2 (configs[1]): 10^6 vis, 2048^2, 16 planes, 7x7
+  cfg5 (configs[4], per-GPU share): 1.25 x 10^8 vis per GPU, 8192^2 grid, 128 planes, 15x15
+  cfg4 (configs[3]): aw-projection (convgrid4), 10^6 vis, 4096^2 grid, 15x15, 128 planes, 512 antennas
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "python"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LDS_ATOMIC_B_PER_CLK = 64.0  # one 64-lane ds_add_f64 (512 B of operands) per 8 LDS cycles per CU
+#                              (tools/micro/lds_atomic.hip, profiles/r01_lds_atomic_microbench.txt)
+FP64_VALU_FLOP_PER_CLK_CU = 128.0  # 4 SIMDs x 16 lanes x FMA (78.6 TFLOP/s vector fp64 at 2.4 GHz)
 
 WORKLOADS = {
     #         n            N     W    Q  S
     "cfg3": (100_000_000, 4096, 128, 8, 15),
     "cfg2": (1_000_000, 2048, 16, 8, 7),
+    "cfg5": (125_000_000, 8192, 128, 8, 15),
+    "cfg4": (1_000_000, 4096, 128, 8, 15),
 }
+AW_ANTENNAS = 512
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--nvis", type=int, default=0, help="override visibilities per GPU")
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "core"])
+    ap.add_argument("--cpu-sample", type=int, default=0, help="visibilities of the CPU baseline's sample (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--collective", default="torch", choices=["torch", "cabi"],
+                    help="N > 1: all-reduce through torch.distributed (nccl = RCCL, overlapped with the next step) or "
+                         "through libgridhip's own RCCL communicator (gridhip_comm_*, on the gridding stream)")
+    ap.add_argument("--opt", action="append", default=[], help="gridhip option key=value (tile, block, chunk, wgroups, variant, sort)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per tile-kernel launch from a separate rocprofv3 --pmc pass "
+                         "(default: profiles/traffic.json if it was measured on this kernel source)")
+    ap.add_argument("--aw-cache", type=int, default=1, help="cfg4: per-key aw-kernel de-duplication (1 = on)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only (gloo, no GPU): checks the rank spawning / environment plumbing on a CPU box")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# plain `python bench.py --gpus N`: spawn the ranks.  Nothing here may touch a GPU (no torch.cuda call, no HIP).
+def spawn_ranks(args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(len(procs)))
+        while pending:
+            for i in sorted(pending):
+                code = procs[i].poll()
+                if code is None:
+                    continue
+                pending.discard(i)
+                if code != 0:
+                    rc = rc or code
+                    for j in pending:  # one rank failed: the others would wait in a collective for ever
+                        procs[j].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
 def alg_bytes_per_vis(S):
     """40 B stream + per tap 16 B kernel read + 16 B grid read + 16 B grid write."""
     return 40 + 48 * S * S
 
 
+def compulsory_bytes_per_vis(n, N, W, Q, S):
+    """SURVEY.md §8(d) B_min: stream once, grid read + written once, kernel table read once."""
+    return 40 + (32.0 * N * N + 16.0 * W * Q * Q * S * S) / n
+
+
 def lds_atomic_cycles_per_vis(S):
-    """LDS cycles the accumulate loop needs per visibility: two ds_add_f64 (re, im) per step of 64 taps, 8 cycles
-    per 64-lane instruction, 7 with three 16-lane groups active, 6 with two or fewer (measured:
-    tools/micro/lds_atomic.hip, profiles/r01_lds_atomic_microbench.txt)."""
+    """LDS cycles the accumulate loop of the tap-reusing tile kernel needs per visibility: two ds_add_f64 (re, im)
+    per step of 64 taps, 8 cycles per 64-lane instruction, 7 with three 16-lane groups active, 6 with two or fewer
+    (measured: tools/micro/lds_atomic.hip, profiles/r01_lds_atomic_microbench.txt)."""
     taps = S * S
     full, tail = divmod(taps, 64)
     cyc = full * 2 * 8
@@ -55,8 +129,51 @@ def lds_atomic_cycles_per_vis(S):
     return cyc
 
 
+def csrc_fingerprint():
+    """sha256 over the sources of the measured kernels (pre-pass + tile kernels): a PMC measurement is only quoted
+    for the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.startswith(("tile_", "bin", "common")) and name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(workload):
+    """HBM bytes per tile-kernel launch from profiles/traffic.json (rocprofv3 --pmc passes, tools/profile.sh), or
+    None when that file was measured on other kernel sources than the ones now in the tree."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[workload]
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC measurement committed for this workload"
+    if rec.get("csrc_sha16") != csrc_fingerprint():
+        return None, "profiles/traffic.json was measured on other kernel sources (csrc_sha16 differs): not quoted"
+    return rec["hbm_bytes_per_launch"], f"profiles/traffic.json ({rec.get('source', 'rocprofv3 --pmc')})"
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def stats(xs):
+    import numpy as np
+    a = np.asarray(xs, dtype=np.float64)
+    return {"mean": float(a.mean()), "median": float(np.median(a)), "min": float(a.min()), "max": float(a.max())}
+
+
+# ---------------------------------------------------------------------------------------------------------
 def synth_kernels(W, Q, S, device):
     """Deterministic smooth complex kernels exp(-r^2/sigma^2) * exp(i*phi(w, r))."""
+    import torch
     j = torch.arange(S, dtype=torch.float64, device=device) - S // 2
     q = torch.arange(Q, dtype=torch.float64, device=device) / Q
     w = torch.arange(W, dtype=torch.float64, device=device)
@@ -69,8 +186,20 @@ def synth_kernels(W, Q, S, device):
     return torch.polar(amp[None].expand(W, Q, Q, S, S).contiguous(), phase).contiguous()
 
 
+def synth_akernels(A, S, device):
+    """Deterministic per-antenna kernels [A,S,S]: a narrow Gaussian with an antenna-dependent phase ramp."""
+    import torch
+    j = torch.arange(S, dtype=torch.float64, device=device) - S // 2
+    a = torch.arange(A, dtype=torch.float64, device=device)
+    r2 = j[:, None] ** 2 + j[None, :] ** 2
+    amp = torch.exp(-r2 / 4.0)
+    phase = 0.01 * (a[:, None, None] + 1.0) * (j[None, :, None] - 0.5 * j[None, None, :])
+    return torch.polar(amp[None].expand(A, S, S).contiguous(), phase).contiguous()
+
+
 def synth_vis(n, N, W, S, seed, device, wstep=2000, dist="uniform"):
-    """Counter-free seeded synthetic stream, generated on the device in slabs."""
+    """Seeded synthetic stream, generated on the device in slabs."""
+    import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     u = torch.empty(n, dtype=torch.float64, device=device)
@@ -102,88 +231,160 @@ def synth_vis(n, N, W, S, seed, device, wstep=2000, dist="uniform"):
     return u, v, wb, vis
 
 
-def cpu_baseline(u, v, wb, vis, gcf, N, sample):
-    """Time the CPU oracle (port of src/Gridding.hs, NOT Accelerate) on a bounded sample."""
+def synth_baselines(n, A, seed, device, dumps_per_key=8):
+    """Baseline-structured antenna pairs for the aw workload: the stream is `dumps_per_key` consecutive time/channel
+    samples of each of n / dumps_per_key random (a1 < a2) pairs — the repetition real data has, where uvw moves
+    slowly along a baseline track (src/ImageDataset.hs:88-104 reads one antenna pair per visibility)."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed ^ 0xA11CE)
+    nb = (n + dumps_per_key - 1) // dumps_per_key
+    a1 = torch.randint(0, A - 1, (nb,), generator=gen, device=device, dtype=torch.int64)
+    a2 = a1 + 1 + (torch.rand(nb, generator=gen, device=device, dtype=torch.float64) * (A - 1 - a1).to(torch.float64)).to(torch.int64)
+    a2 = a2.clamp_(max=A - 1)
+    rep = lambda t: t.repeat_interleave(dumps_per_key)[:n].contiguous()
+    return rep(a1), rep(a2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(u, v, wb, vis, gcf, N, n, sample_override):
+    """Time the CPU oracle (C/OpenMP restatement of src/Gridding.hs:199-244, NOT Accelerate) on a bounded sample,
+    all three of its threading modes; `value` is the best of them."""
+    import numpy as np
     from oracle import gridref_c
     gridref_c.build()
-    hu, hv = u[:sample].cpu().numpy(), v[:sample].cpu().numpy()
-    hw, hvis = wb[:sample].cpu().numpy(), vis[:sample].cpu().numpy()
     hk = gcf.cpu().numpy()
     cores = gridref_c.max_threads()
-    best, mode_best = None, None
-    for mode in (1, 0):  # private grids + reduce, shared grid + atomics
+    names = {0: "shared grid + atomic updates (what a parallel permute (+) does)", 1: "private grids + reduction",
+             2: "owner computes: bands of grid rows, one thread each"}
+    modes = {}
+    for mode in (2, 1, 0):
+        sample = sample_override or (40_000_000 if mode == 2 else 4_000_000)
+        sample = min(sample, n)
+        hu, hv = u[:sample].cpu().numpy(), v[:sample].cpu().numpy()
+        hw, hvis = wb[:sample].cpu().numpy(), vis[:sample].cpu().numpy()
         G = np.zeros((N, N), dtype=np.complex128)
         t0 = time.perf_counter()
         gridref_c.convgrid2(hk, G, hu, hv, hw, hvis, mt_mode=mode, nthreads=cores)
         dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, mode_best = dt, mode
+        modes[names[mode]] = {"Mvis_per_s": sample / dt / 1e6, "sample_vis": sample, "seconds": dt}
+    best = max(modes, key=lambda k: modes[k]["Mvis_per_s"])
     return {
-        "value": sample / best / 1e6,
+        "value": modes[best]["Mvis_per_s"],
         "unit": "Mvis/s",
         "cores": cores,
+        "cpu_model": cpu_model(),
         "kind": "port",
-        "sample": f"first {sample} visibilities of the same workload, C/OpenMP oracle "
-                  f"({'private grids + reduce' if mode_best == 1 else 'shared grid + atomics'}), {best:.2f} s",
+        "sample": f"first {modes[best]['sample_vis']} visibilities of the same workload, C/OpenMP oracle "
+                  f"(oracle/gridref.c, restatement of src/Gridding.hs:199-244; the Accelerate llvm-native path cannot be "
+                  f"built), mode '{best}', {modes[best]['seconds']:.2f} s",
+        "modes": modes,
     }
 
 
+def cpu_baseline_aw(u, v, wb, a1, a2, vis, wk, ak, N, sample):
+    import numpy as np
+    from oracle import gridref_c
+    gridref_c.build()
+    f = lambda t: t[:sample].cpu().numpy()
+    G = np.zeros((N, N), dtype=np.complex128)
+    t0 = time.perf_counter()
+    gridref_c.awgrid(wk.cpu().numpy(), ak.cpu().numpy(), G, f(u), f(v), f(wb), f(a1), f(a2), f(vis))
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt / 1e6, "unit": "Mvis/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"first {sample} visibilities of the same workload, C oracle of convgrid4 (oracle/gridref.c, "
+                      f"FFT-free restatement of src/Gridding.hs:318-396,761-811), single thread, {dt:.2f} s"}
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--nvis", type=int, default=0, help="override visibilities per GPU")
-    ap.add_argument("--dist", default="uniform", choices=["uniform", "core"])
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--opt", action="append", default=[], help="gridhip option key=value (tile, block, chunk, wgroups, variant, sort)")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per tile-kernel launch from a separate rocprofv3 --pmc pass "
-                         "(default: the committed measurement in profiles/traffic.json for this workload)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "python"))
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()),
+                              "workload": args.workload, "vis_per_gpu": WORKLOADS[args.workload][0]}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if torch.cuda.device_count() <= local_rank:  # (counting devices does not initialise the GPU)
+        raise SystemExit(f"rank {rank}: needs GPU {local_rank}, this machine has {torch.cuda.device_count()}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # (GRIDHIP_BENCH_FORCE_DIST=1: run the N > 1 code path - process group, reducer, all-reduce - with one rank,
+    # which is how a one-GPU box exercises it)
+    if world > 1 or os.environ.get("GRIDHIP_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import gridhip
     n, N, W, Q, S = WORKLOADS[args.workload]
     if args.nvis:
         n = args.nvis
+    aw = args.workload == "cfg4"
     ctx = gridhip.Context(local_rank)
     for kv in args.opt:
         k, val = kv.split("=")
         ctx.set_option(k, int(val))
+    if aw:
+        ctx.set_option("aw_cache", args.aw_cache)
 
     gcf = synth_kernels(W, Q, S, device)
     u, v, wb, vis = synth_vis(n, N, W, S, 0x5EEDC0DE + rank, device, dist=args.dist)
+    if aw:
+        akerns = synth_akernels(AW_ANTENNAS, S, device)
+        a1, a2 = synth_baselines(n, AW_ANTENNAS, 0x5EEDC0DE + rank, device)
     G = torch.zeros((N, N), dtype=torch.complex128, device=device)
-    from gridhip.distributed import OverlappedGridReducer
-    # N > 1: one fp64 sum all-reduce of the partial grids per step over xGMI (RCCL), issued on a side
-    # stream so that it overlaps the next step's gridding (two grid buffers used alternately)
-    red = OverlappedGridReducer([G, torch.zeros_like(G)]) if dist is not None else None
+    from gridhip.distributed import Comm, OverlappedGridReducer
+    # N > 1: one fp64 sum all-reduce of the partial grids per step over xGMI (RCCL).  "torch": issued on a side
+    # stream so that it overlaps the next step's gridding (two grid buffers used alternately); "cabi": libgridhip's
+    # own communicator, on the gridding stream.
+    red = comm = None
+    if dist is not None:
+        if args.collective == "torch":
+            red = OverlappedGridReducer([G, torch.zeros_like(G)])
+        else:
+            comm = Comm.from_torch(ctx)
     counter = [0]
 
     def step():
         i = counter[0]
         counter[0] += 1
-        g = red.begin(i) if red else G
-        # this rank's shard of the stream (generated per rank: shard r of a world*n stream)
-        ctx.convgrid2(gcf, g, (u, v, None), wb, vis)
+        g = red.begin(i) if red else G  # (N > 1: the buffer is cleared, each step reduces its own partial grids)
+        if comm:
+            g.zero_()
+        if aw:
+            ctx.convgrid4(gcf, akerns, g, (u, v, None), (wb, a1, a2), vis)
+        else:
+            ctx.convgrid2(gcf, g, (u, v, None), wb, vis)  # this rank's shard (generated per rank)
         if red:
             red.end(i)
+        if comm:
+            comm.allreduce_grid(g)
 
     ctx.enable_timing(True)
     for _ in range(args.warmup):
@@ -194,13 +395,10 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ker_ms, pre_ms = [], []
+    ctx.enable_timing(True)  # restart the event ring: the timed steps are calls 0 .. K-1
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        _, p, k = ctx.last_timing()  # HIP events on the kernels' own stream
-        ker_ms.append(k)
-        pre_ms.append(p)
     if red:
         red.finish()  # every step's all-reduce is complete inside the timed region
     torch.cuda.synchronize()
@@ -208,67 +406,135 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # per-step device times of the timed steps, from HIP events recorded on the kernels' own stream
+    kept = min(args.steps, 64)
+    times = [ctx.timing(back) for back in range(kept)]
+    ker_ms, pre_ms = [t[2] for t in times], [t[1] for t in times]
+    clock_ghz = ctx.get_option("clock_khz") / 1e6
+    errors = ctx.get_option("errors")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    traffic = args.traffic_bytes
-    if traffic is None and not args.opt and not args.nvis and args.dist == "uniform":
-        # PMC counters cannot be collected inside this run; quote the committed rocprofv3 --pmc
-        # measurement of the same workload (tools/profile.sh -> profiles/traffic.json)
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
+    # N > 1: what the collective costs on its own (outside the timed region; gridding and all-reduce separately)
+    multi = None
+    if dist is not None:
+        tg = torch.view_as_real(G)
+        for _ in range(2):
+            dist.all_reduce(tg)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(tg)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 5
+        multi = {"rccl_ranks": dist.get_world_size(), "collective": args.collective,
+                 "allreduce_bytes": int(G.numel() * 16), "allreduce_ms_alone": ar_ms,
+                 "allreduce_busbw_GBps": G.numel() * 16 * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9 if world > 1 else None,
+                 "gridding_ms_per_step": float(np.mean(ker_ms) + np.mean(pre_ms)),
+                 "combined_ms_per_step": elapsed / args.steps * 1e3}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_vis = n * world
         k_avg = float(np.mean(ker_ms))
         props = torch.cuda.get_device_properties(device)
-        clock_ghz = getattr(props, "clock_rate", 2_400_000) / 1e6
-        floor_ms = n * lds_atomic_cycles_per_vis(S) / props.multi_processor_count / (clock_ghz * 1e9) * 1e3
-        lds_floor = {"cycles_per_vis": lds_atomic_cycles_per_vis(S), "cus": props.multi_processor_count,
-                     "clock_GHz": clock_ghz, "floor_ms": floor_ms, "frac": floor_ms / k_avg}
-        achieved = alg_bytes_per_vis(S) * n / (k_avg * 1e-3) / 1e9
+        cus = props.multi_processor_count
+        nominal_ghz = getattr(props, "clock_rate", 2_400_000) / 1e6
+        opts = {k: ctx.get_option(k) for k in ("tile", "block", "chunk", "wgroups", "variant", "sort", "prepass")}
+        if aw:
+            # dominant kernel: the per-key aw-kernel build (fp64 vector ALU): (2S-1)^2-bounded 'same' convolutions
+            info = ctx.aw_stats()
+            flops = info["conv_flops_per_call"]
+            peak = cus * FP64_VALU_FLOP_PER_CLK_CU * nominal_ghz / 1e3  # TFLOP/s
+            achieved = flops / (info["build_ms"] * 1e-3) / 1e12 if info["build_ms"] > 0 else 0.0
+            roof = {"bound": "valu_f64", "kernel": "gridhip::aw_build_kernel (per-key (a1 (*) a2) (*) w 'same' convolutions)",
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "flops_per_launch": flops, "kernel_ms_avg": info["build_ms"], "aw": info}
+            metric = "Mvis/s gridded (aw-proj, 4096^2 grid)"
+            what = f"aw-projection grid (convgrid4): {n} vis/GPU, {N}^2 grid, {W} w-planes, {AW_ANTENNAS} antennas, {S}x{S} support, Q={Q}"
+        else:
+            clk = clock_ghz if clock_ghz > 0.5 else nominal_ghz
+            lds_bytes = 2.0 * S * S * 8.0 * n  # operand bytes of the LDS atomics one launch needs (re + im per tap)
+            achieved = lds_bytes / (k_avg * 1e-3) / 1e9
+            peak = cus * LDS_ATOMIC_B_PER_CLK * clk  # GB/s at the clock the kernel held
+            floor_ms = n * lds_atomic_cycles_per_vis(S) / cus / (clk * 1e9) * 1e3
+            traffic, traffic_src = (args.traffic_bytes, "--traffic-bytes") if args.traffic_bytes else (None, None)
+            if traffic is None and not args.opt and not args.nvis and args.dist == "uniform":
+                traffic, traffic_src = committed_traffic(args.workload)
+            bmin = compulsory_bytes_per_vis(n, N, W, Q, S)
+            alg = alg_bytes_per_vis(S) * n / (k_avg * 1e-3) / 1e9
+            hbm = {"alg_bytes_per_vis": alg_bytes_per_vis(S), "alg_GBps": alg, "alg_over_hbm_peak": alg / HBM_PEAK_GBPS,
+                   "note": "SURVEY §8(d)'s algorithmic figure charges 32 B/tap of grid read-modify-write and 16 B/tap of kernel "
+                           "reads to HBM; the tile design keeps the RMW in LDS and the taps in L2, so alg_over_hbm_peak is "
+                           "not a fraction of anything physical - the bounded figures are roofline.frac (LDS atomic unit) "
+                           "and hbm_measured_frac",
+                   "compulsory_bytes_per_vis": bmin, "traffic_source": traffic_src}
+            if traffic:
+                hbm.update(measured_GBps=traffic / (k_avg * 1e-3) / 1e9,
+                           hbm_measured_frac=traffic / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           traffic_over_compulsory=traffic / (bmin * n))
+            roof = {
+                "bound": "lds_atomic",
+                "kernel": f"gridhip::tile_grid_sorted_kernel<{S},false> (tile_grid_kernel when sort is off)",
+                "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                "traffic": traffic,
+                "what": "LDS-atomic operand bytes per second: 2 x S^2 fp64 ds_add_f64 lane-operations per visibility; "
+                        "peak = CUs x 64 B/clk (one 64-lane ds_add_f64 per 8 LDS cycles) x the shader clock measured "
+                        "inside the kernel",
+                "clock_GHz": clk, "clock_source": "s_memtime / s_memrealtime stamps inside the tile kernel" if clock_ghz > 0.5 else "nominal",
+                "cus": cus, "lds_cycles_per_vis": lds_atomic_cycles_per_vis(S), "lds_floor_ms": floor_ms,
+                "lds_floor_frac": floor_ms / k_avg,
+                "kernel_ms_avg": k_avg, "kernel_ms": stats(ker_ms), "prepass_ms_avg": float(np.mean(pre_ms)),
+                "prepass_ms": stats(pre_ms), "kernel_Mvis_per_s": n / (k_avg * 1e-3) / 1e6,
+                "hbm": hbm,
+            }
+            metric = "Mvis/s gridded (w-proj, 4096^2 grid)" if N == 4096 else f"Mvis/s gridded (w-proj, {N}^2 grid)"
+            what = f"w-projection grid (convgrid2): {n} vis/GPU, {N}^2 grid, {W} w-planes, {S}x{S} support, Q={Q}, {args.dist} uv"
+        for key in ("frac", "lds_floor_frac"):
+            if key in roof:
+                assert 0.0 < roof[key] <= 1.0, f"roofline.{key} = {roof[key]} is not a fraction"
         out = {
-            "metric": "Mvis/s gridded (w-proj, 4096^2 grid)" if args.workload == "cfg3" else "Mvis/s gridded (w-proj)",
+            "metric": metric,
             "value": total_vis / (elapsed / args.steps) / 1e6,
             "unit": "Mvis/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "step_ms_device": stats([a + b for a, b in zip(ker_ms, pre_ms)]),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"w-projection grid (convgrid2): {n} vis/GPU, {N}^2 grid, {W} w-planes, {S}x{S} support, Q={Q}, {args.dist} uv",
+                "workload": what,
+                "name": args.workload,
                 "vis_per_gpu": n, "grid": N, "w_planes": W, "support": S, "oversample": Q,
-                "parallelism": f"vis-sharded x{world}" + (" + RCCL fp64 grid all-reduce per step (overlapped with the next step's gridding)" if world > 1 else ""),
-                "options": {k: ctx.get_option(k) for k in ("tile", "block", "chunk", "wgroups", "variant", "sort")},
+                "parallelism": f"vis-sharded x{world}" + (" + RCCL fp64 grid all-reduce per step" +
+                                                          (" (overlapped with the next step's gridding)" if red else " (libgridhip communicator)")
+                                                          if world > 1 else ""),
+                "scaling_note": "weak: every GPU grids its own vis_per_gpu visibilities; value = n_gpus x vis_per_gpu / step time",
+                "options": opts,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "tile_grid_sorted_kernel<15> (tile_grid_kernel when sort is off)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "alg_bytes_per_vis": alg_bytes_per_vis(S),
-                "kernel_ms_avg": k_avg,
-                "prepass_ms_avg": float(np.mean(pre_ms)),
-                "kernel_Mvis_per_s": n / (k_avg * 1e-3) / 1e6,
-                # what actually binds the kernel: the LDS atomic unit, one per CU
-                "lds_atomic": lds_floor,
-            },
+            "errors": errors,
+            "roofline": roof,
         }
+        if multi:
+            out["multi_gpu"] = multi
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(u, v, wb, vis, gcf, N, min(args.cpu_sample, n))
+            if aw:
+                out["cpu_baseline"] = cpu_baseline_aw(u, v, wb, a1, a2, vis, gcf, akerns, N, min(args.cpu_sample or 20_000, n))
+            else:
+                out["cpu_baseline"] = cpu_baseline(u, v, wb, vis, gcf, N, n, args.cpu_sample)
         print(json.dumps(out), flush=True)
+    if comm:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,6 +28,9 @@
  *   gridhip_<op>      host pointers, synchronous — the drop-in form;
  *   gridhip_<op>_dev  device pointers, asynchronous on the context's stream — what the
  *                     benchmark and multi-GPU drivers use so that H2D is outside the timing.
+ *                     `grid` and `vis_out` must be ordinary device allocations (hipMalloc: coarse-grained
+ *                     memory): the tile kernels flush with hardware fp64 atomics (global_atomic_add_f64),
+ *                     which fine-grained / host-coherent mappings do not support.
  * A context is bound to one device and one stream and is not thread-safe.
  */
 #ifndef GRIDHIP_H
@@ -39,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GRIDHIP_VERSION 100 /* 0.1.0 */
+#define GRIDHIP_VERSION 110 /* 0.1.1 */
 
 #define GRIDHIP_OK 0
 #define GRIDHIP_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
@@ -85,7 +88,8 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               applies from 2^22 visibilities (2 = always)
  *   "dbg"       ablation / profiling switch for tuning runs (0 = off; results are wrong with most values)
  * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel
- * launch (expected 0); "prof0".."prof31" = cycle counters of a dbg=16 launch (tools/phase_profile.py).
+ * launch (expected 0); "clock_khz" = shader clock held during the last tap-reusing tile kernel (in-kernel
+ * s_memtime / s_memrealtime stamps); "prof0".."prof31" = cycle counters of a dbg=16 launch (tools/phase_profile.py).
  */
 int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value);
 int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value);
@@ -211,6 +215,39 @@ int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int
                        const double *u, const double *v, const double *w, int64_t uv_stride,
                        const double *vis, double *image, double *psf, double *pmax);
 
+/* ---- multi-GPU: visibility-sharded gridding + one RCCL fp64 sum all-reduce of the partial grids ------
+ * Gridding is linear in the visibility set, so the path shards by visibility with no data-path exchange; the
+ * partial N x N grids are summed with ncclAllReduce(ncclDouble, ncclSum) over xGMI.  The
+ * reference has no counterpart (single device: app/Main.hs:46-53 picks one (run, runN) pair); these entry points
+ * are what its `aw_gridding` / `do_imaging` callers (src/ImageDataset.hs:72-77, src/Gridding.hs:538-541) would
+ * bind to use a whole node.  RCCL (librccl.so.1) is loaded on first use.
+ *   gridhip_comm_create       ONE process drives ndev devices (ncclCommInitAll); dev_ids NULL = 0..ndev-1.
+ *                             The communicator owns one context per device (gridhip_comm_ctx).
+ *   gridhip_comm_create_rank  one process per GPU (ncclCommInitRank): rank 0 obtains a 128-byte id with
+ *                             gridhip_comm_unique_id and hands it to the other ranks by its own means;
+ *                             `ctx` stays the caller's.
+ * Failures are described by gridhip_comm_last_error (NULL: the last failure before a communicator existed). */
+typedef struct gridhip_comm gridhip_comm;
+int gridhip_comm_create(int ndev, const int *dev_ids, gridhip_comm **comm);
+int gridhip_comm_unique_id(void *id128);
+int gridhip_comm_create_rank(gridhip_ctx *ctx, int nranks, int rank, const void *id128, gridhip_comm **comm);
+int gridhip_comm_destroy(gridhip_comm *comm);
+const char *gridhip_comm_last_error(const gridhip_comm *comm);
+int gridhip_comm_ndev(const gridhip_comm *comm);   /* devices driven by this process */
+int gridhip_comm_nranks(const gridhip_comm *comm); /* devices in the communicator */
+gridhip_ctx *gridhip_comm_ctx(gridhip_comm *comm, int i);
+/* In-place sum over all devices of the communicator of grids[i] (device pointer on this process's i-th device,
+ * `cells` complex cells each); enqueued on each context's stream, asynchronous to the host. */
+int gridhip_comm_allreduce_grids(gridhip_comm *comm, int64_t cells, double *const *grids);
+int gridhip_comm_allreduce_grid(gridhip_comm *comm, int64_t cells, double *grid); /* rank form */
+/* convgrid2 over the communicator, host pointers, synchronous (the drop-in form).  Single-process form: the n
+ * visibilities are cut into contiguous shards, one per device, gridded concurrently, the partial grids all-reduced
+ * and `grid` (accumulated into) returned.  Rank form: every process passes its own shard; the incoming grid is
+ * summed over ranks too, so it should be non-zero on one rank only. */
+int gridhip_comm_convgrid2(gridhip_comm *comm, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W,
+                           int64_t Q, int64_t gh, int64_t gw, const double *gcf, const double *u,
+                           const double *v, int64_t uv_stride, const int64_t *wbin, const double *vis);
+
 /* ---- device memory helpers (so a non-HIP host language can stage buffers) ----------------- */
 int gridhip_malloc(gridhip_ctx *ctx, void **dptr, int64_t bytes);
 int gridhip_free(gridhip_ctx *ctx, void *dptr);
@@ -223,6 +260,9 @@ int gridhip_memset(gridhip_ctx *ctx, void *dptr, int value, int64_t bytes);
  * Synchronises on the recorded events. */
 int gridhip_last_timing(gridhip_ctx *ctx, double *ms_total, double *ms_prepass,
                         double *ms_kernel);
+/* the same for the timed call `back` calls before the last one (0 = the last; the last 64 are kept), so that a
+ * benchmark loop can collect every step's device times after the loop instead of synchronising inside it */
+int gridhip_timing(gridhip_ctx *ctx, int back, double *ms_total, double *ms_prepass, double *ms_kernel);
 int gridhip_enable_timing(gridhip_ctx *ctx, int enable);
 
 #ifdef __cplusplus

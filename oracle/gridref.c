@@ -124,8 +124,8 @@ int gridref_max_threads(void)
 }
 
 /* Timed CPU baseline only (bench.py cpu_baseline).  mode 0 mirrors what a parallel
- * `permute (+)` does (shared destination, atomic element updates); mode 1 is the stronger
- * baseline (private grids, then a reduction). */
+ * `permute (+)` does (shared destination, atomic element updates); mode 1 keeps private grids
+ * and reduces them; mode 2 (the strongest) lets every band of grid rows be updated by one thread. */
 void gridref_convgrid2_mt(int64_t H, int64_t Wd, double *G, int64_t n, int64_t W, int64_t Q,
                           int64_t gh, int64_t gw, const double *gcf, const double *u,
                           const double *v, const int64_t *wbin, const double *vis,
@@ -159,6 +159,54 @@ void gridref_convgrid2_mt(int64_t H, int64_t Wd, double *G, int64_t n, int64_t W
                 }
             }
         }
+    } else if (mode == 2) {
+        /* owner computes: the grid is cut into bands of rows; a band is updated by one thread only, which scans
+         * the footprint rows of every visibility and applies those that fall into its band.  No atomics, no
+         * private grids, and every cell still receives its contributions in visibility order (bit-identical to
+         * the serial oracle).  Bands are handed out dynamically (mirrored data fills only half the grid). */
+        int32_t *y0s = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+        if (!y0s) {
+            gridref_convgrid2(H, Wd, G, n, W, Q, gh, gw, gcf, u, v, wbin, vis);
+            return;
+        }
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        for (int64_t k = 0; k < n; ++k) {
+            int64_t y, yf;
+            frac_coord1(H, Q, v[k], &y, &yf);
+            int64_t y0 = y - idiv2(gh);
+            if (!(v[k] == v[k]) || y0 < -(int64_t)1000000000 || y0 > (int64_t)1000000000) y0 = 1000000000; /* outside */
+            y0s[k] = (int32_t)y0;
+        }
+        int64_t band = gh > 32 ? gh : 32;
+        int64_t nbands = (H + band - 1) / band;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+        for (int64_t b = 0; b < nbands; ++b) {
+            int64_t r0 = b * band, r1 = r0 + band < H ? r0 + band : H;
+            for (int64_t k = 0; k < n; ++k) {
+                int64_t y0 = y0s[k];
+                if (y0 >= r1 || y0 + gh <= r0) continue;
+                int64_t x, xf, y, yf;
+                frac_coord1(Wd, Q, u[k], &x, &xf);
+                frac_coord1(H, Q, v[k], &y, &yf);
+                int64_t x0 = x - idiv2(gw);
+                int64_t wb = wbin ? wbin[k] : 0;
+                const double *kk = gcf + 2 * ((((wb * Q) + yf) * Q + xf) * gh * gw);
+                double vr = vis[2 * k], vi = vis[2 * k + 1];
+                int64_t i0 = r0 > y0 ? r0 - y0 : 0, i1 = r1 - y0 < gh ? r1 - y0 : gh;
+                for (int64_t i = i0; i < i1; ++i) {
+                    int64_t yy = y0 + i;
+                    for (int64_t j = 0; j < gw; ++j) {
+                        int64_t xx = x0 + j;
+                        if (xx < 0 || xx >= Wd) continue;
+                        double kr = kk[2 * (i * gw + j)], ki = kk[2 * (i * gw + j) + 1];
+                        double *g = G + 2 * (yy * Wd + xx);
+                        g[0] += vr * kr - vi * ki;
+                        g[1] += vr * ki + vi * kr;
+                    }
+                }
+            }
+        }
+        free(y0s);
     } else {
         size_t cells = (size_t)H * (size_t)Wd * 2;
         double *priv = (double *)calloc(cells * (size_t)nthreads, sizeof(double));

@@ -21,9 +21,18 @@ int check_common(gridhip_ctx *ctx, int64_t H, int64_t Wd, const void *grid, int6
     return GRIDHIP_OK;
 }
 
+// i = 0: a timed call starts, 1: its pre-pass is enqueued, 2: its dominant kernel is enqueued (the call is then
+// readable with gridhip_timing)
 void mark(gridhip_ctx *ctx, int i)
 {
-    if (ctx->timing) (void)hipEventRecord(ctx->ev[i], ctx->stream);
+    if (!ctx->timing) return;
+    if (i == 0) ctx->ev_open = true;
+    if (!ctx->ev_open) return;
+    (void)hipEventRecord(ctx->ev[(ctx->ev_calls % gridhip_ctx::EV_RING) * 3 + i], ctx->stream);
+    if (i == 2) {
+        ctx->ev_open = false;
+        ++ctx->ev_calls;
+    }
 }
 
 
@@ -95,7 +104,6 @@ static int pipelined_convgrid2(gridhip_ctx *ctx, const Geom &g, int block, size_
     mark(ctx, 2);
     GH_CHECK_HIP(ctx, hipEventRecord(pb.tile_done, ctx->stream));
     pb.used = true;
-    ctx->ev_valid = ctx->timing;
     return GRIDHIP_OK;
 }
 
@@ -128,7 +136,6 @@ int gridhip_grid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int6
     mark(ctx, 1);
     GH_CHECK(launch_simple_grid(ctx, H, Wd, grid, n, u, v, uv_stride, vis));
     mark(ctx, 2);
-    ctx->ev_valid = ctx->timing;
     return GRIDHIP_OK;
 }
 
@@ -145,8 +152,7 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
         mark(ctx, 1);
         GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
         mark(ctx, 2);
-        ctx->ev_valid = ctx->timing;
-        return GRIDHIP_OK;
+            return GRIDHIP_OK;
     }
     Geom g;
     int block;
@@ -158,8 +164,7 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
         mark(ctx, 1);
         GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
         mark(ctx, 2);
-        ctx->ev_valid = ctx->timing;
-        return GRIDHIP_OK;
+            return GRIDHIP_OK;
     }
     GH_CHECK(rc);
     // tap-reusing variant: the work item's records are sorted by slice in LDS, which bounds the chunk
@@ -186,7 +191,6 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
             GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, vis, grid));
     }
     mark(ctx, 2);
-    ctx->ev_valid = ctx->timing;
     return GRIDHIP_OK;
 }
 
@@ -230,7 +234,6 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
             GH_CHECK(launch_tile_degrid(ctx, g, block, lds, n, gcf, grid, vis_out));
     }
     mark(ctx, 2);
-    ctx->ev_valid = ctx->timing;
     return GRIDHIP_OK;
 }
 

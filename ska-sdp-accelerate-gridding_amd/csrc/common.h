@@ -66,7 +66,8 @@ struct gridhip_ctx {
     gridhip::Workspace recs_raw;   // unbinned records + bin numbers of a pre-pass that runs beside a tile kernel (bin.hip)
     gridhip::Workspace recs_tmp;   // coarse-binned records between the two scatter levels of the pre-pass (bin.hip)
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
-    int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [2]=errors, [4..11] work queues, [32..] profile
+    int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=aw drops, [2]=errors, [4..19] work queues,
+                                   // [20..27] clock stamps of the last sorted tile kernel, [32..] profile
     int32_t *bin_scalars = nullptr;  // where the pre-pass counts (d_scalars, or a pipeline buffer's own 16 ints)
     bool pre_light = false;  // the pre-pass being launched runs beside a tile kernel (bin.hip)
     // async_prepass: a call's pre-pass runs on pre_stream into one of two record/table sets while the previous
@@ -84,8 +85,12 @@ struct gridhip_ctx {
     int num_cu = 256;
     int max_lds = 160 * 1024;
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    // HIP events of the last EV_RING timed device calls (3 per call: start, pre-pass done, kernel done), so that a
+    // benchmark loop can read every step's device times afterwards instead of synchronising inside the loop
+    static constexpr int EV_RING = 64;
+    hipEvent_t ev[EV_RING * 3] = {};
+    int64_t ev_calls = 0;  // timed calls recorded so far; call c uses slots (c % EV_RING) * 3 ...
+    bool ev_open = false;  // a call has recorded its first event and not yet its last
     uint32_t attr_mask = 0;  // pre-pass kernels whose dynamic-LDS limit has been raised
     std::unordered_set<const void *> lds_raised;  // tile kernels whose dynamic-LDS limit has been raised
     void *fft_plan = nullptr;  // cached hipFFT Z2Z plan (imaging.hip)

@@ -220,7 +220,7 @@ int gridhip_create(int device, gridhip_ctx **out)
         return GRIDHIP_ENOMEM;
     }
     ctx->bin_scalars = ctx->d_scalars;
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < gridhip_ctx::EV_RING * 3; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
             gridhip_destroy(ctx);
             return GRIDHIP_EHIP;
@@ -240,7 +240,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < gridhip_ctx::EV_RING * 3; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (auto &pb : ctx->pipe) {
         if (pb.pre_done) (void)hipEventDestroy(pb.pre_done);
@@ -318,6 +318,17 @@ int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value)
         *value = h;
         return GRIDHIP_OK;
     }
+    if (!strcmp(key, "clock_khz")) {
+        // read-only: shader clock held during the last sorted tile kernel, from the s_memtime / s_memrealtime
+        // (100 MHz) stamps its first work-group takes when it starts and when its queues are empty
+        GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+        int64_t h[4] = {0, 0, 0, 0};
+        GH_CHECK_HIP(ctx, hipMemcpyAsync(h, ctx->d_scalars + 20, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t cyc = h[2] - h[0], ticks = h[3] - h[1];
+        *value = ticks > 0 && cyc > 0 ? (int64_t)((double)cyc / (double)ticks * 1e5) : 0;
+        return GRIDHIP_OK;
+    }
     if (!strncmp(key, "prof", 4) && key[4] >= '0' && key[4] <= '9') {
         // read-only: cycles summed over work-groups by a dbg=16 tuning launch of the sorted kernel
         // (0..6: per phase, thread 0; 8..23: the accumulate walk of wave 0..15)
@@ -387,22 +398,31 @@ int gridhip_enable_timing(gridhip_ctx *ctx, int enable)
 {
     if (!ctx) return GRIDHIP_EINVAL;
     ctx->timing = enable != 0;
-    ctx->ev_valid = false;
+    ctx->ev_calls = 0;
+    ctx->ev_open = false;
+    return GRIDHIP_OK;
+}
+
+int gridhip_timing(gridhip_ctx *ctx, int back, double *ms_total, double *ms_prepass, double *ms_kernel)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    if (back < 0 || back >= gridhip_ctx::EV_RING || back >= ctx->ev_calls)
+        return fail(ctx, GRIDHIP_EINVAL, "no timed call recorded %d calls back (gridhip_enable_timing; the last %d are kept)",
+                    back, gridhip_ctx::EV_RING);
+    hipEvent_t *e = ctx->ev + ((ctx->ev_calls - 1 - back) % gridhip_ctx::EV_RING) * 3;
+    GH_CHECK_HIP(ctx, hipEventSynchronize(e[2]));
+    float pre = 0.f, ker = 0.f;
+    GH_CHECK_HIP(ctx, hipEventElapsedTime(&pre, e[0], e[1]));
+    GH_CHECK_HIP(ctx, hipEventElapsedTime(&ker, e[1], e[2]));
+    if (ms_prepass) *ms_prepass = pre;
+    if (ms_kernel) *ms_kernel = ker;
+    if (ms_total) *ms_total = (double)pre + (double)ker;
     return GRIDHIP_OK;
 }
 
 int gridhip_last_timing(gridhip_ctx *ctx, double *ms_total, double *ms_prepass, double *ms_kernel)
 {
-    if (!ctx) return GRIDHIP_EINVAL;
-    if (!ctx->ev_valid) return fail(ctx, GRIDHIP_EINVAL, "no timed call recorded (gridhip_enable_timing)");
-    GH_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[2]));
-    float pre = 0.f, ker = 0.f;
-    GH_CHECK_HIP(ctx, hipEventElapsedTime(&pre, ctx->ev[0], ctx->ev[1]));
-    GH_CHECK_HIP(ctx, hipEventElapsedTime(&ker, ctx->ev[1], ctx->ev[2]));
-    if (ms_prepass) *ms_prepass = pre;
-    if (ms_kernel) *ms_kernel = ker;
-    if (ms_total) *ms_total = (double)pre + (double)ker;
-    return GRIDHIP_OK;
+    return gridhip_timing(ctx, 0, ms_total, ms_prepass, ms_kernel);
 }
 
 int gridhip_last_dropped(gridhip_ctx *ctx, int64_t *dropped)

@@ -94,6 +94,13 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
     const int nwalk = solo ? 1 : nw - 1;
     const int ncell = g.lrows * g.lcols;
 
+    // shader clock held during this launch (option "clock_khz"): the first work-group stamps the cycle counter and
+    // the 100 MHz real-time counter when it starts and when the queues are empty (two scalar stores per launch)
+    if (blockIdx.x == 0 && tid == 0) {
+        long long *st = reinterpret_cast<long long *>(scalars + 20);
+        st[0] = (long long)__builtin_amdgcn_s_memtime();
+        st[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
     long long prof[7] = {0, 0, 0, 0, 0, 0, 0}, pt = 0;  // ABL & 16: cycles per phase, first lane of the stamping wave
 #define GH_STAMP(i_)                        \
     if ((ABL & 16) && lane == 0) {          \
@@ -525,6 +532,11 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
         }
         __syncthreads();
         if ((ABL & 16) && wave == 0) GH_STAMP(6)  // flush
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        long long *st = reinterpret_cast<long long *>(scalars + 20);
+        st[2] = (long long)__builtin_amdgcn_s_memtime();
+        st[3] = (long long)__builtin_amdgcn_s_memrealtime();
     }
     if ((ABL & 16) && lane == 0 && (wave == 0 || (is_sorter && !solo))) {
         unsigned long long *out = reinterpret_cast<unsigned long long *>(scalars + 32);

@@ -36,7 +36,8 @@ def _split_p(p):
         return p[0], p[1], 1
     if p.ndim == 2 and p.shape[1] == 3:
         if _is_torch(p):
-            p = p.contiguous()
+            import torch
+            p = p.to(torch.float64).contiguous()  # (the library reads doubles at stride 3)
             return p[:, 0], p[:, 1], 3
         p = np.ascontiguousarray(p, dtype=np.float64)
         return p[:, 0], p[:, 1], 3
@@ -97,6 +98,12 @@ class Context:
         """(total_ms, prepass_ms, kernel_ms) of the last device call, from HIP events on the stream."""
         t, p, k = C.c_double(), C.c_double(), C.c_double()
         self._check(self._lib.gridhip_last_timing(self._h, C.byref(t), C.byref(p), C.byref(k)))
+        return t.value, p.value, k.value
+
+    def timing(self, back=0):
+        """(total_ms, prepass_ms, kernel_ms) of the timed device call `back` calls before the last one."""
+        t, p, k = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.gridhip_timing(self._h, int(back), C.byref(t), C.byref(p), C.byref(k)))
         return t.value, p.value, k.value
 
     def last_dropped(self):

@@ -64,12 +64,24 @@ SIGNATURES = {
                                 vp, vp]),
     "gridhip_do_imaging": (ci, [vp, ci, i64, i64, i64, i64, i64, vp, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp,
                                 vp, C.POINTER(C.c_double)]),
+    "gridhip_comm_create": (ci, [ci, C.POINTER(ci), C.POINTER(vp)]),
+    "gridhip_comm_unique_id": (ci, [vp]),
+    "gridhip_comm_create_rank": (ci, [vp, ci, ci, vp, C.POINTER(vp)]),
+    "gridhip_comm_destroy": (ci, [vp]),
+    "gridhip_comm_last_error": (C.c_char_p, [vp]),
+    "gridhip_comm_ndev": (ci, [vp]),
+    "gridhip_comm_nranks": (ci, [vp]),
+    "gridhip_comm_ctx": (vp, [vp, ci]),
+    "gridhip_comm_allreduce_grids": (ci, [vp, i64, C.POINTER(vp)]),
+    "gridhip_comm_allreduce_grid": (ci, [vp, i64, vp]),
+    "gridhip_comm_convgrid2": (ci, [vp] + _CONV2_DEV[1:]),
     "gridhip_malloc": (ci, [vp, C.POINTER(vp), i64]),
     "gridhip_free": (ci, [vp, vp]),
     "gridhip_memcpy_h2d": (ci, [vp, vp, vp, i64]),
     "gridhip_memcpy_d2h": (ci, [vp, vp, vp, i64]),
     "gridhip_memset": (ci, [vp, vp, ci, i64]),
     "gridhip_last_timing": (ci, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gridhip_timing": (ci, [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gridhip_enable_timing": (ci, [vp, ci]),
 }
 

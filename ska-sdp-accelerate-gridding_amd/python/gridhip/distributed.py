@@ -48,11 +48,15 @@ class OverlappedGridReducer:
         self.comm = torch.cuda.Stream(device=grids[0].device)
         self.work = [None, None]
 
-    def begin(self, i):
+    def begin(self, i, zero=True):
+        """The buffer step i grids onto.  Its previous reduction is waited for and (zero=True) it is cleared:
+        a step's all-reduce sums this step's partial grids, not the previous step's reduced content again."""
         w = self.work[i % 2]
         if w is not None:
             w.wait()  # this buffer's previous reduction must finish before it is written again
             self.work[i % 2] = None
+        if zero:
+            self.grids[i % 2].zero_()
         return self.grids[i % 2]
 
     def end(self, i):
@@ -84,3 +88,97 @@ def sharded_convgrid2(gridder, gcf, a, p, wbin, v, rank, world, group=None, redu
     if reduce and world > 1:
         allreduce_grid(a, group)
     return a
+
+
+class Comm:
+    """libgridhip's own RCCL communicator (include/gridhip.h, gridhip_comm_*): the multi-GPU surface a
+    non-Python host binds.  Comm.single_process(ndev) drives ndev devices from this process
+    (ncclCommInitAll); Comm.from_torch(ctx) is the one-process-per-GPU form, the 128-byte id travelling
+    over the already initialised torch.distributed group."""
+
+    def __init__(self, handle, lib, ctxs=None):
+        self._h, self._lib, self.ctxs = handle, lib, ctxs or []
+
+    @staticmethod
+    def _err(lib, rc, h=None):
+        from ._lib import GridHipError
+        return GridHipError(rc, (lib.gridhip_comm_last_error(h) or b"").decode())
+
+    @classmethod
+    def single_process(cls, ndev, dev_ids=None):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        h = C.c_void_p()
+        ids = (C.c_int * ndev)(*dev_ids) if dev_ids is not None else None
+        rc = lib.gridhip_comm_create(int(ndev), ids, C.byref(h))
+        if rc != 0:
+            raise cls._err(lib, rc)
+        return cls(h, lib)
+
+    @classmethod
+    def from_torch(cls, ctx, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        lib = _lib.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            rc = lib.gridhip_comm_unique_id(buf)
+            if rc != 0:
+                raise cls._err(lib, rc)
+        dev = torch.device("cuda", ctx.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
+        dist.broadcast(t, src=0, group=group)
+        ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        h = C.c_void_p()
+        rc = lib.gridhip_comm_create_rank(ctx._h, world, rank, ident, C.byref(h))
+        if rc != 0:
+            raise cls._err(lib, rc)
+        return cls(h, lib, [ctx])
+
+    @property
+    def ndev(self):
+        return self._lib.gridhip_comm_ndev(self._h)
+
+    @property
+    def nranks(self):
+        return self._lib.gridhip_comm_nranks(self._h)
+
+    def allreduce_grid(self, grid):
+        """In-place fp64 sum over the communicator of a cuda complex128 tensor (rank form), enqueued on the
+        context's stream."""
+        import ctypes as C
+        rc = self._lib.gridhip_comm_allreduce_grid(self._h, grid.numel(), C.c_void_p(grid.data_ptr()))
+        if rc != 0:
+            raise self._err(self._lib, rc, self._h)
+        return grid
+
+    def convgrid2(self, gcf, a, p, wbin, v):
+        """convgrid2 over all devices of the communicator, numpy host arrays (gridhip_comm_convgrid2)."""
+        import ctypes as C
+        gcf = np.ascontiguousarray(gcf, dtype=np.complex128)
+        u, vv = np.ascontiguousarray(p[0], dtype=np.float64), np.ascontiguousarray(p[1], dtype=np.float64)
+        vis = np.ascontiguousarray(v, dtype=np.complex128)
+        wb = None if wbin is None else np.ascontiguousarray(wbin, dtype=np.int64)
+        assert a.dtype == np.complex128 and a.flags.c_contiguous
+        W, Q, _, gh, gw = gcf.shape
+        ptr = lambda x: None if x is None else C.c_void_p(x.ctypes.data)
+        rc = self._lib.gridhip_comm_convgrid2(self._h, a.shape[0], a.shape[1], ptr(a), len(u), W, Q, gh, gw, ptr(gcf),
+                                              ptr(u), ptr(vv), 1, ptr(wb), ptr(vis))
+        if rc != 0:
+            raise self._err(self._lib, rc, self._h)
+        return a
+
+    def close(self):
+        if self._h:
+            self._lib.gridhip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

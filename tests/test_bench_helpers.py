@@ -28,3 +28,65 @@ def test_lds_atomic_cycles_per_visibility(S, cycles):
 def test_workloads_are_the_baseline_configs():
     assert bench.WORKLOADS["cfg3"] == (100_000_000, 4096, 128, 8, 15)
     assert bench.WORKLOADS["cfg2"] == (1_000_000, 2048, 16, 8, 7)
+    assert bench.WORKLOADS["cfg5"] == (125_000_000, 8192, 128, 8, 15)  # 10^9 visibilities over 8 GPUs
+    assert bench.WORKLOADS["cfg4"][1:] == (4096, 128, 8, 15)
+
+
+def test_compulsory_bytes_per_visibility():
+    # SURVEY.md §8(d) B_min: 40 + (32 N^2 + 16 W Q^2 S^2) / n  -> 45.7 B/vis in the headline configuration
+    assert bench.compulsory_bytes_per_vis(10**8, 4096, 128, 8, 15) == pytest.approx(45.66, abs=0.01)
+
+
+def test_lds_atomic_peak_matches_the_cycle_floor():
+    # the byte-rate form of the bound (roofline.achieved / peak) and the cycle form (lds_floor_ms) agree where
+    # the tap count packs perfectly into 64-lane instructions
+    S, n, cus, clk = 16, 10**8, 256, 2.1
+    floor_ms = n * bench.lds_atomic_cycles_per_vis(S) / cus / (clk * 1e9) * 1e3
+    peak = cus * bench.LDS_ATOMIC_B_PER_CLK * clk  # GB/s
+    assert 2 * S * S * 8 * n / (peak * 1e9) * 1e3 == pytest.approx(floor_ms)
+
+
+def test_traffic_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    import json
+    import os
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "ska-sdp-accelerate-gridding_amd" / "csrc")
+    (tmp_path / "ska-sdp-accelerate-gridding_amd" / "csrc" / "tile_k.hip").write_text("// v1\n")
+    fp = bench.csrc_fingerprint()
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps({"cfg3": {"hbm_bytes_per_launch": 1e9, "csrc_sha16": fp}}))
+    assert bench.committed_traffic("cfg3")[0] == 1e9
+    (tmp_path / "ska-sdp-accelerate-gridding_amd" / "csrc" / "tile_k.hip").write_text("// v2\n")
+    assert bench.committed_traffic("cfg3")[0] is None
+    assert bench.committed_traffic("cfg2")[0] is None
+
+
+def test_plain_command_spawns_the_ranks():
+    """`python bench.py --gpus 2` as a plain command starts the two rank processes itself (before any GPU call) and
+    relays rank 0's line; --dry-run keeps the rendezvous on gloo so this runs on a CPU box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--dry-run", "--workload", "cfg5"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rank_sum"] == 3.0 and rec["vis_per_gpu"] == 125_000_000
+
+
+def test_a_failing_rank_ends_the_job():
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    # without --dry-run the ranks need GPUs; on a CPU box every rank exits non-zero and so must the parent
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    out = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0

@@ -1,0 +1,133 @@
+"""The N > 1 code on hardware.  A one-GPU box cannot show scaling, but it can run every line of the multi-GPU path
+with a communicator of one rank: an `nccl` (= RCCL) process group drives OverlappedGridReducer (side stream, events,
+two buffers), libgridhip's own communicator (gridhip_comm_*) all-reduces and grids, and bench.py runs its N > 1 branch.
+Each case runs in a fresh child process so that the process group exists before anything touches the GPU."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PRELUDE = textwrap.dedent(f"""
+    import os, sys
+    sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "ska-sdp-accelerate-gridding_amd", "python"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import numpy as np, torch, torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import gridhip
+    from gridhip.distributed import OverlappedGridReducer, Comm, allreduce_grid
+    from oracle import gridref_c
+    rng = np.random.default_rng(7)
+    N, W, Q, S, n = 192, 8, 4, 9, 60000
+    gcf = rng.normal(size=(W, Q, Q, S, S)) + 1j * rng.normal(size=(W, Q, Q, S, S))
+    us = [rng.uniform(-0.5, 0.5, n) for _ in range(5)]
+    vs = [rng.uniform(-0.5, 0.5, n) for _ in range(5)]
+    wb = rng.integers(0, W, n)
+    vis = rng.normal(size=n) + 1j * rng.normal(size=n)
+    refs = [gridref_c.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), us[i], vs[i], wb, vis) for i in range(5)]
+    T = lambda a, dt=None: torch.as_tensor(a, device=dev)
+    ctx = gridhip.Context(0)
+    relerr = lambda g, r: float(np.abs(g - r).max() / np.abs(r).max())
+""")
+
+
+def run_child(body):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-c", PRELUDE + textwrap.dedent(body)], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_overlapped_reducer_on_an_nccl_group_of_one():
+    """five steps over two buffers: every reduced grid equals that step's plain convgrid2 (the buffer is cleared in
+    begin(), the previous reduction is waited for, the side stream is ordered after the gridding)"""
+    rec = run_child("""
+        bufs = [torch.zeros((N, N), dtype=torch.complex128, device=dev) for _ in range(2)]
+        red = OverlappedGridReducer(bufs)
+        tg, tw, tv = T(gcf), T(wb), T(vis)
+        errs, results = [], []
+        for i in range(5):
+            g = red.begin(i)
+            ctx.convgrid2(tg, g, (T(us[i]), T(vs[i]), None), tw, tv)
+            red.end(i)
+            if i >= 1:  # the previous step's buffer: its reduction runs beside this step's gridding
+                red.work[(i - 1) % 2].wait()
+                errs.append(relerr(bufs[(i - 1) % 2].cpu().numpy(), refs[i - 1]))
+        red.finish()
+        errs.append(relerr(bufs[4 % 2].cpu().numpy(), refs[4]))
+        import json; print(json.dumps({"errs": errs, "errors": ctx.get_option("errors")}))
+        dist.destroy_process_group()
+    """)
+    assert len(rec["errs"]) == 5 and max(rec["errs"]) < 1e-10 and rec["errors"] == 0
+
+
+def test_cabi_communicator_rank_form_and_single_process_form():
+    rec = run_child("""
+        import json
+        # rank form: the id travels over the torch group; all-reduce of one rank leaves the grid unchanged
+        comm = Comm.from_torch(ctx)
+        g = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+        ctx.convgrid2(T(gcf), g, (T(us[0]), T(vs[0]), None), T(wb), T(vis))
+        comm.allreduce_grid(g)
+        ctx.synchronize()
+        e_rank = relerr(g.cpu().numpy(), refs[0])
+        sizes = (comm.ndev, comm.nranks)
+        comm.close()
+        # single-process form (what a Haskell host binds): shards, grids, reduces and accumulates INTO the host grid
+        comm1 = Comm.single_process(1)
+        start = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+        G = start.copy()
+        comm1.convgrid2(gcf, G, (us[1], vs[1], None), wb, vis)
+        e_single = relerr(G - start, refs[1])
+        # n = 0 and bad arguments
+        G0 = start.copy(); comm1.convgrid2(gcf, G0, (us[1][:0], vs[1][:0], None), wb[:0], vis[:0])
+        same = bool(np.array_equal(G0, start))
+        comm1.close()
+        bad = None
+        try:
+            Comm.single_process(2, [0, 0])
+        except gridhip.GridHipError as e:
+            bad = e.code
+        print(json.dumps({"e_rank": e_rank, "e_single": e_single, "sizes": sizes, "same": same, "bad": bad}))
+        dist.destroy_process_group()
+    """)
+    assert rec["e_rank"] < 1e-10 and rec["e_single"] < 1e-10
+    assert rec["sizes"] == [1, 1] and rec["same"] and rec["bad"] == -1
+
+
+@pytest.mark.parametrize("collective", ["torch", "cabi"])
+def test_bench_multi_gpu_branch_with_one_rank(collective):
+    """bench.py's N > 1 branch (process group, reducer / communicator, all-reduce timing, multi_gpu record)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(GRIDHIP_BENCH_FORCE_DIST="1", MASTER_PORT="29535")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nvis",
+                          "3000000", "--no-cpu", "--collective", collective], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-4000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["multi_gpu"]["rccl_ranks"] == 1 and rec["multi_gpu"]["collective"] == collective
+    assert rec["multi_gpu"]["allreduce_ms_alone"] > 0 and rec["errors"] == 0
+    assert 0 < rec["roofline"]["frac"] <= 1 and 0 < rec["roofline"]["lds_floor_frac"] <= 1
+    assert rec["roofline"]["bound"] == "lds_atomic" and 1.0 < rec["roofline"]["clock_GHz"] < 2.6
+
+
+def test_bench_default_line_is_bounded():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nvis",
+                          "4000000", "--cpu-sample", "200000"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-4000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    r = rec["roofline"]
+    assert 0 < r["frac"] <= 1 and 0 < r["lds_floor_frac"] <= 1 and r["kernel_ms"]["min"] <= r["kernel_ms"]["median"]
+    assert rec["cpu_baseline"]["cores"] >= 1 and len(rec["cpu_baseline"]["modes"]) == 3
+    assert rec["cpu_baseline"]["cpu_model"] and rec["value"] > 0
