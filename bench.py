@@ -261,18 +261,20 @@ def cpu_baseline(u, v, wb, vis, gcf, N, n, sample_override):
     for mode in (2, 1, 0):
         sample = sample_override or (40_000_000 if mode == 2 else 4_000_000)
         sample = min(sample, n)
+        # (private grids: 16 threads at most - every thread zeroes and reduces its own N x N grid)
+        threads = min(cores, 16) if mode == 1 else cores
         hu, hv = u[:sample].cpu().numpy(), v[:sample].cpu().numpy()
         hw, hvis = wb[:sample].cpu().numpy(), vis[:sample].cpu().numpy()
         G = np.zeros((N, N), dtype=np.complex128)
         t0 = time.perf_counter()
-        gridref_c.convgrid2(hk, G, hu, hv, hw, hvis, mt_mode=mode, nthreads=cores)
+        gridref_c.convgrid2(hk, G, hu, hv, hw, hvis, mt_mode=mode, nthreads=threads)
         dt = time.perf_counter() - t0
-        modes[names[mode]] = {"Mvis_per_s": sample / dt / 1e6, "sample_vis": sample, "seconds": dt}
+        modes[names[mode]] = {"Mvis_per_s": sample / dt / 1e6, "sample_vis": sample, "seconds": dt, "threads": threads}
     best = max(modes, key=lambda k: modes[k]["Mvis_per_s"])
     return {
         "value": modes[best]["Mvis_per_s"],
         "unit": "Mvis/s",
-        "cores": cores,
+        "cores": modes[best]["threads"],
         "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"first {modes[best]['sample_vis']} visibilities of the same workload, C/OpenMP oracle "

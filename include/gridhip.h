@@ -79,13 +79,14 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *   "sort"      order each work item's records by kernel slice so that runs of visibilities
  *               reuse their taps from registers: 0 = auto, 1 = on (when the shape allows), 2 = off
  *   "prepass"   scatter of the binning pre-pass: 0 = auto (two levels from 2^22 visibilities), 1 = one level,
- *               2 = two levels (LDS-sorted runs into coarse bins, then into the bins), 3 = one level with global
- *               atomics only (no LDS; a measured baseline: 16 ms against 2.1 ms at 10^8 visibilities)
- *   "async_prepass"  1 = the coordinate arrays (u, v, wbin) given to gridhip_convgrid2_dev are complete when the
- *               call is made (not the product of work still queued on the stream): the binning pre-pass of a call
- *               then runs on an internal stream beside the previous call's tile kernel (two record sets
- *               alternate); grid updates stay on the caller's stream in call order.  0 = off (default);
- *               applies from 2^22 visibilities (2 = always)
+ *               2 = two levels (the counting sweep leaves 8-byte pre-records, which are LDS-sorted into runs per
+ *               coarse bin and then per bin), 3 = one level with global atomics only (no LDS; a measured
+ *               baseline), 4 = two levels recomputing from the stream instead of reading pre-records,
+ *               5 = two levels with 16-byte instead of 12-byte intermediate records
+ *   "aw_cache"  aw gridders: 1 (default) = build each distinct (a1, a2, wbin, yf, xf) kernel once per call and let
+ *               the visibilities that share it reuse it; 0 = one kernel per visibility (as the reference evaluates)
+ *   "fault_inject"  TEST HOOK: hides the last k slots of the record array from the pre-pass's scatter so that its
+ *               bounds checks have something to reject (counted in "errors"; results are then incomplete)
  *   "dbg"       ablation / profiling switch for tuning runs (0 = off; results are wrong with most values)
  * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel
  * launch (expected 0); "clock_khz" = shader clock held during the last tap-reusing tile kernel (in-kernel

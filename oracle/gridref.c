@@ -163,7 +163,8 @@ void gridref_convgrid2_mt(int64_t H, int64_t Wd, double *G, int64_t n, int64_t W
         /* owner computes: the grid is cut into bands of rows; a band is updated by one thread only, which scans
          * the footprint rows of every visibility and applies those that fall into its band.  No atomics, no
          * private grids, and every cell still receives its contributions in visibility order (bit-identical to
-         * the serial oracle).  Bands are handed out dynamically (mirrored data fills only half the grid). */
+         * the serial oracle).  Bands are handed out dynamically (mirrored data fills only half the grid).
+         * n < 2^31 (indices are kept as int32). */
         int32_t *y0s = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
         if (!y0s) {
             gridref_convgrid2(H, Wd, G, n, W, Q, gh, gw, gcf, u, v, wbin, vis);
@@ -177,14 +178,63 @@ void gridref_convgrid2_mt(int64_t H, int64_t Wd, double *G, int64_t n, int64_t W
             if (!(v[k] == v[k]) || y0 < -(int64_t)1000000000 || y0 > (int64_t)1000000000) y0 = 1000000000; /* outside */
             y0s[k] = (int32_t)y0;
         }
+        /* every visibility is listed under the one or two bands its footprint rows touch (band height >= gh), in
+         * visibility order: per-thread counts -> offsets -> fill */
         int64_t band = gh > 32 ? gh : 32;
         int64_t nbands = (H + band - 1) / band;
+        int64_t *cnt = (int64_t *)calloc((size_t)(nbands + 1) * (size_t)nthreads + 1, sizeof(int64_t));
+        int64_t *start = (int64_t *)malloc((size_t)(nbands + 1) * sizeof(int64_t));
+        int32_t *list = NULL;
+        if (cnt && start) {
+#pragma omp parallel num_threads(nthreads)
+            {
+                int t = omp_get_thread_num(), nt = omp_get_num_threads();
+                int64_t k0 = n * t / nt, k1 = n * (t + 1) / nt;
+                int64_t *mine = cnt + (size_t)t * (size_t)(nbands + 1);
+                for (int64_t k = k0; k < k1; ++k) {
+                    int64_t y0 = y0s[k];
+                    if (y0 >= H || y0 + gh <= 0) continue;
+                    int64_t b0 = y0 < 0 ? 0 : y0 / band, b1 = (y0 + gh - 1) / band;
+                    if (b1 >= nbands) b1 = nbands - 1;
+                    for (int64_t b = b0; b <= b1; ++b) ++mine[b];
+                }
+            }
+            int64_t run = 0;
+            for (int64_t b = 0; b < nbands; ++b) {
+                start[b] = run;
+                for (int t = 0; t < nthreads; ++t) {
+                    int64_t c = cnt[(size_t)t * (size_t)(nbands + 1) + (size_t)b];
+                    cnt[(size_t)t * (size_t)(nbands + 1) + (size_t)b] = run;
+                    run += c;
+                }
+            }
+            start[nbands] = run;
+            list = (int32_t *)malloc((size_t)(run > 0 ? run : 1) * sizeof(int32_t));
+        }
+        if (!list) {
+            free(cnt); free(start); free(y0s);
+            gridref_convgrid2(H, Wd, G, n, W, Q, gh, gw, gcf, u, v, wbin, vis);
+            return;
+        }
+#pragma omp parallel num_threads(nthreads)
+        {
+            int t = omp_get_thread_num(), nt = omp_get_num_threads();
+            int64_t k0 = n * t / nt, k1 = n * (t + 1) / nt;
+            int64_t *mine = cnt + (size_t)t * (size_t)(nbands + 1);
+            for (int64_t k = k0; k < k1; ++k) {
+                int64_t y0 = y0s[k];
+                if (y0 >= H || y0 + gh <= 0) continue;
+                int64_t b0 = y0 < 0 ? 0 : y0 / band, b1 = (y0 + gh - 1) / band;
+                if (b1 >= nbands) b1 = nbands - 1;
+                for (int64_t b = b0; b <= b1; ++b) list[mine[b]++] = (int32_t)k;
+            }
+        }
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
         for (int64_t b = 0; b < nbands; ++b) {
             int64_t r0 = b * band, r1 = r0 + band < H ? r0 + band : H;
-            for (int64_t k = 0; k < n; ++k) {
+            for (int64_t q = start[b]; q < start[b + 1]; ++q) {
+                int64_t k = list[q];
                 int64_t y0 = y0s[k];
-                if (y0 >= r1 || y0 + gh <= r0) continue;
                 int64_t x, xf, y, yf;
                 frac_coord1(Wd, Q, u[k], &x, &xf);
                 frac_coord1(H, Q, v[k], &y, &yf);
@@ -206,6 +256,7 @@ void gridref_convgrid2_mt(int64_t H, int64_t Wd, double *G, int64_t n, int64_t W
                 }
             }
         }
+        free(list); free(cnt); free(start);
         free(y0s);
     } else {
         size_t cells = (size_t)H * (size_t)Wd * 2;

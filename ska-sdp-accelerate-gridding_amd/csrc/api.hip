@@ -1,8 +1,6 @@
 // C-ABI entry points of the gridders (include/gridhip.h): argument checks, the device-pointer
 // forms that enqueue the kernels, and the host-pointer drop-in forms that stage through HBM.
 
-#include <utility>
-
 #include "common.h"
 
 using namespace gridhip;
@@ -36,77 +34,6 @@ void mark(gridhip_ctx *ctx, int i)
 }
 
 
-// Option "async_prepass": the caller promises that the coordinate arrays (u, v, wbin) handed to a gridding call are
-// complete when the call is made - not the product of work still queued on the stream.  The binning pre-pass of
-// call i+1 then runs on a side stream BESIDE call i's tile kernel: that kernel is bound by the LDS atomic unit and
-// leaves the memory system, half the wave slots and 44 KB of LDS per CU idle, which is what the pre-pass wants
-// (bin.hip, `light` sizes).  Two sets of records / tables alternate; the tile kernels stay on ctx->stream in call
-// order, so everything the caller enqueues after a call is still ordered after that call's grid update.
-static int pipelined_convgrid2(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_sorted, int nkeys, int maxchunk,
-                               int64_t n, const double *gcf, const double *u, const double *v, int64_t uv_stride,
-                               const int64_t *wbin, const double *vis, double *grid)
-{
-    if (!ctx->pre_stream) {
-        GH_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking));
-        GH_CHECK_HIP(ctx, hipMalloc((void **)&ctx->pipe_scalars, 2 * 16 * sizeof(int32_t)));
-        GH_CHECK_HIP(ctx, hipMemset(ctx->pipe_scalars, 0, 2 * 16 * sizeof(int32_t)));
-        GH_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_order, hipEventDisableTiming));
-        for (auto &pb : ctx->pipe) {
-            GH_CHECK_HIP(ctx, hipEventCreateWithFlags(&pb.pre_done, hipEventDisableTiming));
-            GH_CHECK_HIP(ctx, hipEventCreateWithFlags(&pb.tile_done, hipEventDisableTiming));
-        }
-    }
-    const int b = ctx->pipe_idx ^= 1;
-    gridhip_ctx::PipeBuf &pb = ctx->pipe[b];
-    // the launchers read the binned data from the context's scratch slots: lend them this buffer's
-    struct Lend {
-        gridhip_ctx *c;
-        gridhip_ctx::PipeBuf &p;
-        Lend(gridhip_ctx *c_, gridhip_ctx::PipeBuf &p_) : c(c_), p(p_)
-        {
-            std::swap(c->recs, p.recs);
-            std::swap(c->tables, p.tables);
-        }
-        ~Lend()
-        {
-            std::swap(c->recs, p.recs);
-            std::swap(c->tables, p.tables);
-        }
-    } lend(ctx, pb);
-    // scratch is sized before the timed region begins (growing synchronises the device)
-    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)n * sizeof(VisRec)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)n * sizeof(VisRec)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs_raw, (size_t)n * (sizeof(VisRec) + sizeof(int32_t)) + 256));
-    mark(ctx, 0);
-    // the tile kernel that read this buffer two calls ago must be done before it is overwritten; a pre-pass
-    // that ran on the main stream in between shares the temporaries with this one
-    if (pb.used) GH_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->pre_stream, pb.tile_done, 0));
-    if (ctx->main_binned) {
-        GH_CHECK_HIP(ctx, hipEventRecord(ctx->pipe_order, ctx->stream));
-        GH_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->pre_stream, ctx->pipe_order, 0));
-        ctx->main_binned = false;
-    }
-    {
-        hipStream_t main = ctx->stream;
-        ctx->stream = ctx->pre_stream;
-        ctx->pre_light = true;
-        ctx->bin_scalars = ctx->pipe_scalars + 16 * b;
-        const int rc = launch_bin(ctx, g, n, u, v, uv_stride, wbin);
-        ctx->pre_light = false;
-        ctx->stream = main;
-        GH_CHECK(rc);
-    }
-    GH_CHECK_HIP(ctx, hipEventRecord(pb.pre_done, ctx->pre_stream));
-    GH_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, pb.pre_done, 0));
-    mark(ctx, 1);
-    GH_CHECK(launch_tile_grid_sorted(ctx, g, block, lds_sorted, nkeys, maxchunk, n, gcf, vis, grid, false));
-    mark(ctx, 2);
-    GH_CHECK_HIP(ctx, hipEventRecord(pb.tile_done, ctx->stream));
-    pb.used = true;
-    return GRIDHIP_OK;
-}
-
 // bump allocator over the staging workspace
 struct Stage {
     char *base;
@@ -121,6 +48,18 @@ struct Stage {
 };
 
 size_t aligned(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// the host-pointer forms are synchronous: an internal consistency failure of the call (a record that did not fit
+// the record array, a slice index outside the kernel table - the caller's arrays changed during the call, or a
+// bug) is reported instead of a silently incomplete grid
+int check_errors(gridhip_ctx *ctx)
+{
+    int32_t e = 0;
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(&e, ctx->d_scalars + 2, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (e) return fail(ctx, GRIDHIP_EINVAL, "internal consistency check failed for %d records (inputs modified during the call?)", e);
+    return GRIDHIP_OK;
+}
 
 }  // namespace
 
@@ -175,9 +114,6 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
     const bool sorted = want_sort && sorted_plan(ctx, g, block, &nkeys, &maxchunk, &lds_sorted);
     // a sorted work item may span several LDS batches; keep it big enough to flush each tile once
     if (sorted) g.chunk = maxchunk;
-    // (2 = also for small streams: tests)
-    if (sorted && n > 0 && (ctx->opt.async_prepass == 2 || (ctx->opt.async_prepass == 1 && n >= ((int64_t)1 << 22))))
-        return pipelined_convgrid2(ctx, g, block, lds_sorted, nkeys, maxchunk, n, gcf, u, v, uv_stride, wbin, vis, grid);
     // scratch is sized before the timed region begins
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
@@ -254,6 +190,7 @@ int grid_per_vis_kernels(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, 
     ctx->opt.wgroups = keep;
     GH_CHECK(rc);
     g.per_vis = 1;
+    g.nslices = g.nvis;  // one private slice per visibility
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
     GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, nullptr));
@@ -323,6 +260,7 @@ int gridhip_convgrid2(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int
     if (n) GH_CHECK_HIP(ctx, hipMemcpyAsync(dvis, vis, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
     if (n && wbin) GH_CHECK_HIP(ctx, hipMemcpyAsync(dwb, wbin, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     GH_CHECK(gridhip_convgrid2_dev(ctx, H, Wd, dg, n, W, Q, gh, gw, dk, du, dv, uv_stride, wbin ? dwb : nullptr, dvis));
+    if (ctx->opt.variant != 1) GH_CHECK(check_errors(ctx));  // (before the grid is handed back)
     GH_CHECK_HIP(ctx, hipMemcpyAsync(grid, dg, cells * 16, hipMemcpyDeviceToHost, ctx->stream));
     GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GRIDHIP_OK;
@@ -357,6 +295,7 @@ int gridhip_degrid2(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *grid,
     GH_CHECK_HIP(ctx, hipMemcpyAsync(dk, gcf, kel * 16, hipMemcpyHostToDevice, ctx->stream));
     if (n && wbin) GH_CHECK_HIP(ctx, hipMemcpyAsync(dwb, wbin, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     GH_CHECK(gridhip_degrid2_dev(ctx, H, Wd, dg, n, W, Q, gh, gw, dk, du, dv, uv_stride, wbin ? dwb : nullptr, dvis));
+    GH_CHECK(check_errors(ctx));
     if (n) GH_CHECK_HIP(ctx, hipMemcpyAsync(vis_out, dvis, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
     GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GRIDHIP_OK;

@@ -282,7 +282,6 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         return fail(ctx, GRIDHIP_EINVAL, "bad argument");
     if (S > 63 || A > 46340 || n > (int64_t)0x7fffff00) return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside aw limits");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->bin_scalars = ctx->d_scalars;
     GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16 * sizeof(int32_t), ctx->stream));
     if (n == 0) return GRIDHIP_OK;
     const size_t S2 = (size_t)S * S, pairs = (size_t)A * A;

@@ -1,51 +1,38 @@
-// Binning pre-pass: turn the caller's (u, v, wbin, vis) stream into tile-ordered VisRec
-// records so that the tile kernels can accumulate a whole grid tile in LDS.
+// Binning pre-pass: turn the caller's (u, v, wbin) stream into tile-ordered VisRec records so that
+// the tile kernels can accumulate a whole grid tile in LDS.
 //
-//   bin_count   : histogram of visibilities per bin (bin = w-group x grid tile), LDS-privatised; each
-//                 work-group also keeps its own histogram
-//   bin_scan    : exclusive scans -> bin_start[], per-group work_start[] (chunks of <=chunk vis)
+//   bin_count   : the ONLY sweep over the caller's stream (24 B per visibility) and the only place the fp64
+//                 coordinate arithmetic is done.  Histogram of visibilities per bin (bin = w-group x grid tile),
+//                 LDS-privatised; for large streams it also leaves an 8-byte PRE-RECORD per visibility
+//                 (bin | lx | ly | kslice) for the scatter
+//   bin_scan    : exclusive scans -> bin_start[], per-group work_start[] (chunks of <= chunk visibilities)
+//
+// Small streams (< 2^22 visibilities) then write each record straight to its bin:
 //   bin_offsets : per-work-group histograms -> each work-group's first slot in every bin
-//   bin_scatter : second sweep writes each visibility's VisRec into its work-group's slot range
+//   bin_scatter : a second sweep over the stream writes each visibility's VisRec into its work-group's range
+// A record written straight to its bin is a lone 12-byte store into one of ~10^5 open regions, i.e. one
+// partial-line HBM write per visibility (2.6 ms for 10^8 records against 0.45 ms for the counting sweep), so
+// large streams scatter in two levels, both through an LDS counting sort so that records leave the CU as
+// contiguous runs (option "prepass": 0 = auto, 1 = one level, 2 = two levels, 3 = one level with global atomics
+// only, 4 = two levels recomputing from the stream instead of reading pre-records, 5 = two levels with 16-byte
+// intermediate records):
+//   coarse_scatter : chunks of 8192 pre-records are counting-sorted by COARSE bin (2^k consecutive bins) in LDS
+//                    and written as runs into a temporary array laid out like the final one at coarse
+//                    granularity (one global atomic per chunk and non-empty coarse bin reserves the run's place)
+//   fine_scatter   : equal shares of the temporary array (a chunk spans one or two coarse bins, so few open
+//                    lines per work-group) are sorted by bin the same way and written to the final array
+// Bytes per visibility: 24 read + 8 written (count), 8 + 12 (coarse), 12 + 12 (fine) = 76 B, against 98 B when
+// both scatter levels recomputed from the stream and records were 16 B.  Because the scatter no longer reads the
+// caller's arrays, the count and the scatter cannot disagree (a caller overwriting u, v, wbin during the call
+// changes which records are produced, never where they are written); every record store is bounds-checked
+// against the array all the same and violations are counted (option "errors").
 //
-// Large streams take the scatter in two levels instead (option "prepass": 0 = auto, 1 = one level,
-// 2 = two levels).  A record written straight to its bin is a lone 16-byte store into one of ~10^5
-// open regions, i.e. one partial-line HBM write per visibility, which is what bounds the one-level
-// sweep (2.6 ms for 10^8 records against 0.45 ms for the counting sweep over the same input).
-//   coarse_scatter : chunks of 8192 visibilities are counting-sorted by COARSE bin (2^k consecutive
-//                    bins) in LDS and written as runs into a temporary array laid out like the final
-//                    one at coarse granularity
-//   fine_scatter   : segments of the temporary array (a handful of coarse bins each, so few open
-//                    lines per work-group: the L2 merges them) are distributed to their bins
-//
-// Coordinates follow frac_coords / convgrid2 of src/Gridding.hs:126-151,212-218: the footprint
-// origin is (x - gw/2, y - gh/2); a visibility none of whose taps can land inside the grid is
-// dropped here (fixoutofbounds would drop every one of its taps, :883-891).
+// Coordinates follow frac_coords / convgrid2 of src/Gridding.hs:126-151,212-218: the footprint origin is
+// (x - gw/2, y - gh/2); a visibility none of whose taps can land inside the grid is dropped here (fixoutofbounds
+// would drop every one of its taps, :883-891).
 #include "common.h"
 
 namespace gridhip {
-
-#ifndef LIGHT_PRIO
-#define LIGHT_PRIO 3  // wave priority of the kernels that run beside a tile kernel (async_prepass): they finish in
-                      // 5.8 ms instead of 9.8 ms, the tile kernel loses the same 1.6 ms either way
-#endif
-
-// streaming accesses of the kernels that run beside a tile kernel carry the non-temporal hint: they should not
-// displace the kernel table (L2, Infinity Cache) the tile kernel lives on
-typedef int nt_i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int4 ld_nt(const int4 *p)
-{
-    const nt_i4 a = __builtin_nontemporal_load(reinterpret_cast<const nt_i4 *>(p));
-    return make_int4(a.x, a.y, a.z, a.w);
-}
-__device__ __forceinline__ void st_nt(int4 *p, int4 v)
-{
-    nt_i4 a;
-    a.x = v.x;
-    a.y = v.y;
-    a.z = v.z;
-    a.w = v.w;
-    __builtin_nontemporal_store(a, reinterpret_cast<nt_i4 *>(p));
-}
 
 struct BinOut {
     int32_t bin;  // -1: no tap in the grid, -2: wbin outside [0,W)
@@ -84,6 +71,77 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
     return o;
 }
 
+// ---- pre-records ------------------------------------------------------------------------------
+// What the counting sweep computed, one 8-byte word per visibility (bin | lx | ly | kslice, the bin's width from
+// the geometry; all ones = dropped); the visibility's index is its position.
+struct PreFmt {
+    int bin_bits;  // bits of the bin field (bin_count_kernel: negated = count FROM the pre-records)
+};
+static inline int bits_for(int64_t count)  // bits that hold 0 .. count-1
+{
+    int b = 1;
+    while (((int64_t)1 << b) < count) ++b;
+    return b;
+}
+__device__ __forceinline__ unsigned long long pre_pack(const PreFmt f, const BinOut &b)
+{
+    if (b.bin < 0) return ~0ull;
+    const unsigned long long lx = (unsigned)b.lxy & 0x7f, ly = ((unsigned)b.lxy >> 16) & 0x7f;
+    return (unsigned long long)(unsigned)b.bin | lx << f.bin_bits | ly << (f.bin_bits + 7) |
+           (unsigned long long)(unsigned)b.kslice << (f.bin_bits + 14);
+}
+__device__ __forceinline__ BinOut pre_unpack(const PreFmt f, unsigned long long p)
+{
+    BinOut b;
+    if (p == ~0ull) {
+        b.bin = -1;
+        b.lxy = 0;
+        b.kslice = 0;
+        return b;
+    }
+    b.bin = (int32_t)(p & ((1ull << f.bin_bits) - 1));
+    const int32_t lx = (int32_t)(p >> f.bin_bits) & 0x7f, ly = (int32_t)(p >> (f.bin_bits + 7)) & 0x7f;
+    b.lxy = (ly << 16) | lx;
+    b.kslice = (int32_t)(p >> (f.bin_bits + 14));
+    return b;
+}
+
+// ---- records between the two scatter levels -------------------------------------------------------
+// The final record plus its bin.  T12: 12 bytes, the bin in the 18 bits of lxy that lx and ly (7 bits each, tiles
+// are at most 128 cells) leave free - bins < 2^18; otherwise 16 bytes with the bin in a fourth word.
+constexpr int TMP12_MAX_BINS = 1 << 18;
+template <bool T12>
+struct TmpRec;
+template <>
+struct TmpRec<true> {
+    int32_t lxy, kslice, orig;
+    __device__ __forceinline__ void set(int32_t lxy_, int32_t ks, int32_t o, int32_t bin)
+    {
+        lxy = lxy_ | ((bin & 0x1ff) << 7) | ((bin >> 9) << 23);
+        kslice = ks;
+        orig = o;
+    }
+    __device__ __forceinline__ int32_t bin() const
+    {
+        return (int32_t)(((uint32_t)lxy >> 7) & 0x1ff) | (int32_t)(((uint32_t)lxy >> 23) << 9);
+    }
+    __device__ __forceinline__ VisRec final_rec() const { return VisRec{lxy & 0x007f007f, kslice, orig}; }
+};
+template <>
+struct TmpRec<false> {
+    int32_t lxy, kslice, orig, b;
+    __device__ __forceinline__ void set(int32_t lxy_, int32_t ks, int32_t o, int32_t bin)
+    {
+        lxy = lxy_;
+        kslice = ks;
+        orig = o;
+        b = bin;
+    }
+    __device__ __forceinline__ int32_t bin() const { return b; }
+    __device__ __forceinline__ VisRec final_rec() const { return VisRec{lxy, kslice, orig}; }
+};
+static_assert(sizeof(TmpRec<true>) == 12 && sizeof(TmpRec<false>) == 16, "record sizes");
+
 // Each block owns one contiguous slice of the stream (the same slice in both sweeps).
 __device__ __forceinline__ void block_range(int64_t n, int64_t *lo, int64_t *hi)
 {
@@ -100,15 +158,14 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
                                                          const int64_t *__restrict__ wbin,
                                                          int32_t *__restrict__ bin_count,
                                                          int32_t *__restrict__ block_hist,
-                                                         int32_t *__restrict__ scalars, int bin_lo, int bin_hi)
+                                                         int32_t *__restrict__ scalars, int bin_lo, int bin_hi,
+                                                         PreFmt pf, unsigned long long *__restrict__ pre)
 {
     // LDS_HIST: this launch handles the bins [bin_lo, bin_hi) only (a window that fits in LDS); grids
-    // with more bins than that are covered by several launches, each a full sweep of the stream.
+    // with more bins than that are covered by several launches.  pre != null: the first window's launch leaves
+    // the pre-record of every visibility, the others (pf.bin_bits < 0) count from those.
     extern __shared__ int32_t hist[];
     const int nwin = bin_hi - bin_lo;
-    // 512-thread launches run beside a tile kernel (async_prepass): few instructions, all of them feeding memory
-    // requests, so they go first at the SIMD's arbiter (which otherwise favours the tile kernel's older waves)
-    if (LIGHT_PRIO && blockDim.x == 512) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < nwin; i += blockDim.x) hist[i] = 0;
         __syncthreads();
@@ -116,8 +173,16 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
     int64_t lo, hi;
     block_range(n, &lo, &hi);
     int dropped = 0;
+    const bool from_pre = pre && pf.bin_bits < 0;
+    const PreFmt rf = {from_pre ? -pf.bin_bits : pf.bin_bits};
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
+        BinOut b;
+        if (from_pre)
+            b = pre_unpack(rf, pre[k]);
+        else {
+            b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
+            if (pre) pre[k] = pre_pack(rf, b);
+        }
         if (b.bin >= 0) {
             if (LDS_HIST) {
                 if (b.bin >= bin_lo && b.bin < bin_hi) atomicAdd(&hist[b.bin - bin_lo], 1);
@@ -237,6 +302,8 @@ __global__ void __launch_bounds__(NT) bin_scan_kernel(Geom g, const int32_t *__r
     }
 }
 
+// One-level scatter (small streams).  `cap` = record slots the array holds: a slot outside it is never written
+// (it can only arise if the caller's arrays changed between the two sweeps) and is counted in scalars[2].
 template <bool LDS_HIST>
 __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
                                                            const double *__restrict__ v, int64_t stride,
@@ -244,7 +311,8 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
                                                            const int32_t *__restrict__ bin_start,
                                                            int32_t *__restrict__ cursor,
                                                            const int32_t *__restrict__ block_hist,
-                                                           VisRec *__restrict__ recs, int bin_lo, int bin_hi)
+                                                           VisRec *__restrict__ recs, int bin_lo, int bin_hi,
+                                                           int32_t cap, int32_t *__restrict__ scalars)
 {
     extern __shared__ int32_t hist[];
     int64_t lo, hi;
@@ -255,7 +323,7 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
         for (int i = threadIdx.x; i < bin_hi - bin_lo; i += blockDim.x) hist[i] = mine[i];
         __syncthreads();
     }
-    // write the records
+    int bad = 0;
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
         if (b.bin < 0) continue;
@@ -265,112 +333,16 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
             slot = atomicAdd(&hist[b.bin - bin_lo], 1);
         else
             slot = bin_start[b.bin] + atomicAdd(&cursor[b.bin], 1);
-        VisRec r;
-        r.lxy = b.lxy;
-        r.kslice = b.kslice;
-        r.orig = (int32_t)k;
-        r.pad = 0;
-        *reinterpret_cast<int4 *>(recs + slot) = *reinterpret_cast<const int4 *>(&r);  // one 16-B store
-    }
-}
-
-// ---- pre-pass beside a tile kernel (async_prepass) -------------------------------------------
-// The coordinate arithmetic (fp64 floor / round / conversions, ~100 instructions per visibility) is what a
-// co-resident pre-pass costs the tile kernel most - issue slots, not bandwidth - and the LDS the tile kernel
-// leaves (44 KB) holds a quarter of the bin histogram.  So this form does the arithmetic ONCE, leaving unbinned
-// records and a compact array of bin numbers; the histogram is then counted from the bin numbers in four
-// windows (4 x 0.4 GB, no arithmetic) and the coarse scatter reads the records instead of the coordinates.
-__global__ void __launch_bounds__(512) light_records_kernel(Geom g, int64_t n, const double *__restrict__ u,
-                                                            const double *__restrict__ v, int64_t stride,
-                                                            const int64_t *__restrict__ wbin,
-                                                            VisRec *__restrict__ raw, int32_t *__restrict__ bins,
-                                                            int32_t *__restrict__ scalars)
-{
-    if (LIGHT_PRIO) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
-    int dropped = 0;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
-        const BinOut b = vis_bin(g, __builtin_nontemporal_load(u + k * stride), __builtin_nontemporal_load(v + k * stride),
-                                 wbin ? __builtin_nontemporal_load(wbin + k) : 0, k);
-        if (b.bin == -2) ++dropped;
-        st_nt(reinterpret_cast<int4 *>(raw + k), make_int4(b.lxy, b.kslice, (int32_t)k, b.bin));
-        __builtin_nontemporal_store(b.bin, bins + k);
-    }
-    if (dropped) atomicAdd(&scalars[0], dropped);
-}
-
-__global__ void __launch_bounds__(512) light_count_kernel(int64_t n, const int32_t *__restrict__ bins,
-                                                          int32_t *__restrict__ bin_count, int bin_lo, int bin_hi)
-{
-    extern __shared__ int32_t hist[];
-    if (LIGHT_PRIO) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
-    const int nwin = bin_hi - bin_lo;
-    for (int i = threadIdx.x; i < nwin; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    const int64_t n4 = n / 4;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
-        const int4 b = ld_nt(reinterpret_cast<const int4 *>(bins) + k);
-        if (b.x >= bin_lo && b.x < bin_hi) atomicAdd(&hist[b.x - bin_lo], 1);
-        if (b.y >= bin_lo && b.y < bin_hi) atomicAdd(&hist[b.y - bin_lo], 1);
-        if (b.z >= bin_lo && b.z < bin_hi) atomicAdd(&hist[b.z - bin_lo], 1);
-        if (b.w >= bin_lo && b.w < bin_hi) atomicAdd(&hist[b.w - bin_lo], 1);
-    }
-    if (blockIdx.x == 0)
-        for (int64_t k = n4 * 4 + threadIdx.x; k < n; k += blockDim.x) {
-            const int b = bins[k];
-            if (b >= bin_lo && b < bin_hi) atomicAdd(&hist[b - bin_lo], 1);
+        if ((uint32_t)slot >= (uint32_t)cap) {
+            ++bad;
+            continue;
         }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
-        const int c = hist[i];
-        if (c) atomicAdd(&bin_count[bin_lo + i], c);
+        recs[slot] = VisRec{b.lxy, b.kslice, (int32_t)k};
     }
-}
-
-// Coarse-bin counts of every work-group's slice of the stream (the slices of coarse_scatter_kernel), and their
-// conversion into each work-group's first slot per coarse bin.  With these the coarse scatter beside a tile kernel
-// reserves nothing at run time: its reservations would be ~25 M returning atomics on ~500 addresses, and hot-spot
-// atomics in L2 are what a co-resident kernel must not do - 24 M of them slow the tile kernel from 14 to 20 ms,
-// while the same number spread over 34 K addresses, or 17 GB of plain copies, cost it nothing
-// (tools/coresidency_probe.py).
-__global__ void __launch_bounds__(512) light_coarse_count_kernel(int64_t n, const int32_t *__restrict__ bins, int shift,
-                                                                 int ncoarse, int32_t *__restrict__ wcnt)
-{
-    extern __shared__ int32_t hist[];
-    if (LIGHT_PRIO) __builtin_amdgcn_s_setprio(LIGHT_PRIO);
-    for (int i = threadIdx.x; i < ncoarse; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    int64_t lo, hi;
-    block_range(n, &lo, &hi);
-    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        const int b = __builtin_nontemporal_load(bins + k);
-        if (b >= 0) atomicAdd(&hist[b >> shift], 1);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ncoarse; i += blockDim.x) wcnt[(size_t)blockIdx.x * ncoarse + i] = hist[i];
-}
-
-// wcnt[w][c] (count) -> first slot of work-group w inside coarse bin c's region.  One thread per coarse bin.
-__global__ void __launch_bounds__(256) light_coarse_offsets_kernel(int ncoarse, int nwg, int shift,
-                                                                   const int32_t *__restrict__ bin_start,
-                                                                   int32_t *__restrict__ wcnt)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncoarse) return;
-    int run = bin_start[c << shift];
-    for (int w = 0; w < nwg; ++w) {
-        int32_t *p = wcnt + (size_t)w * ncoarse + c;
-        const int cnt = *p;
-        *p = run;
-        run += cnt;
-    }
+    if (bad) atomicAdd(&scalars[2], bad);
 }
 
 // ---- two-level scatter ----------------------------------------------------------------------
-// Both levels exist in two sizes: <1024 threads, 8192-record chunks> (128 KB of records in LDS, one work-group per
-// CU; 4096-record chunks at two per CU measured 0.1 ms slower) for a pre-pass that has the chip to itself, and <512, 2048> (37-41 KB of LDS, 64 registers) for one that runs
-// on a side stream BESIDE the previous call's tile kernel, whose persistent work-groups leave 44 KB of LDS, half
-// the wave slots and a quarter of the registers of every CU free (option "async_prepass").
-
 // In-place exclusive scan of hist[0..nent), nent <= 1024, by NT threads (consecutive entries per thread);
 // reserve(e, count, base) is called for every non-empty entry; wtot[16] receives the total.
 template <int NT, typename F>
@@ -410,29 +382,28 @@ __device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *w
 // Level 1.  tmp is laid out like the final record array at coarse granularity: coarse bin c owns
 // [bin_start[c << shift], bin_start[min((c + 1) << shift, nbins)]).  Each chunk reserves, per coarse bin, a
 // contiguous range there (one global atomic per chunk and non-empty coarse bin) and writes its records as
-// runs; the record's spare word carries its bin for level 2.
-template <int NT, int CHUNK, bool FROM_RECS = false>
-__global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
-                                                            const double *__restrict__ v, int64_t stride,
-                                                            const int64_t *__restrict__ wbin,
-                                                            const int32_t *__restrict__ bin_start,
-                                                            int32_t *__restrict__ ccur, int shift, int ncoarse,
-                                                            VisRec *__restrict__ tmp, const VisRec *__restrict__ raw,
-                                                            const int32_t *__restrict__ woff)
+// runs; the record carries its bin for level 2.
+// FROM_PRE: the chunk is read from the counting sweep's pre-records; otherwise it is recomputed from the stream.
+template <int NT, int CHUNK, bool FROM_PRE, bool T12>
+__global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
+                                                               const double *__restrict__ v, int64_t stride,
+                                                               const int64_t *__restrict__ wbin,
+                                                               const int32_t *__restrict__ bin_start,
+                                                               int32_t *__restrict__ ccur, int shift, int ncoarse,
+                                                               TmpRec<T12> *__restrict__ tmp,
+                                                               const unsigned long long *__restrict__ pre, PreFmt pf,
+                                                               int32_t cap, int32_t *__restrict__ scalars)
 {
     extern __shared__ int32_t smem[];
-    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [CHUNK]
-    int32_t *hist = smem + CHUNK * 4;                   // [ncoarse]: count, then the coarse bin's first slot in `sorted`
-    int32_t *gbase = hist + ncoarse;                    // [ncoarse]: tmp position of sorted[0] if it were in this bin
-    int32_t *wtot = gbase + ncoarse;                    // [16] per-wave totals of the scan, [16] = chunk total
-    int32_t *lcur = wtot + 32;                          // [ncoarse] (FROM_RECS): this work-group's next slot per coarse bin
+    TmpRec<T12> *sorted = reinterpret_cast<TmpRec<T12> *>(smem);  // [CHUNK]
+    int32_t *hist = smem + CHUNK * (sizeof(TmpRec<T12>) / 4);     // [ncoarse]: count, then the coarse bin's first slot in `sorted`
+    int32_t *gbase = hist + ncoarse;                              // [ncoarse]: tmp position of sorted[0] if it were in this bin
+    int32_t *wtot = gbase + ncoarse;                              // [16] per-wave totals of the scan, [16] = chunk total
     const int tid = threadIdx.x;
     constexpr int PER = CHUNK / NT;
-    if (LIGHT_PRIO && NT == 512) __builtin_amdgcn_s_setprio(LIGHT_PRIO);  // beside a tile kernel: see bin_count_kernel
     int64_t lo, hi;
     block_range(n, &lo, &hi);
-    if (FROM_RECS)
-        for (int i = tid; i < ncoarse; i += NT) lcur[i] = woff[(size_t)blockIdx.x * ncoarse + i];
+    int bad = 0;
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         for (int i = tid; i < ncoarse; i += NT) hist[i] = 0;
         __syncthreads();
@@ -443,13 +414,11 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel
             const int64_t k = c0 + q * NT + tid;
             b[q].bin = -1;
             if (k < hi) {
-                if (FROM_RECS) {  // (light_records_kernel has done the arithmetic)
-                    const int4 r = ld_nt(reinterpret_cast<const int4 *>(raw + k));
-                    b[q].lxy = r.x;
-                    b[q].kslice = r.y;
-                    b[q].bin = r.w;
-                } else
+                if (FROM_PRE)
+                    b[q] = pre_unpack(pf, pre[k]);
+                else
                     b[q] = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
+                if (b[q].bin >= g.nbins) b[q].bin = -1;  // (cannot happen)
             }
         }
 #pragma unroll
@@ -458,36 +427,30 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel
         __syncthreads();
         // exclusive scan of the counts and the global reservations
         scan_entries<NT>(hist, ncoarse, wtot, [&](int e, int c, int base) {
-            if (FROM_RECS) {  // slots fixed beforehand (light_coarse_offsets_kernel): no atomics beside a tile kernel
-                const int first = lcur[e];
-                lcur[e] = first + c;
-                gbase[e] = first - base;
-            } else
-                gbase[e] = bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
+            gbase[e] = bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
         });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             if (b[q].bin < 0) continue;
-            VisRec r;
-            r.lxy = b[q].lxy;
-            r.kslice = b[q].kslice;
-            r.orig = (int32_t)(c0 + q * NT + tid);
-            r.pad = b[q].bin;
+            TmpRec<T12> r;
+            r.set(b[q].lxy, b[q].kslice, (int32_t)(c0 + q * NT + tid), b[q].bin);
             sorted[hist[b[q].bin >> shift] + rank[q]] = r;
         }
         __syncthreads();
         const int total = wtot[16];
         for (int i = tid; i < total; i += NT) {
-            const int4 r = *reinterpret_cast<const int4 *>(sorted + i);
-            int4 *dst = reinterpret_cast<int4 *>(tmp + gbase[r.w >> shift] + i);  // neighbouring lanes: neighbouring slots
-            if (NT == 512)
-                st_nt(dst, r);
-            else
-                *dst = r;
+            const TmpRec<T12> r = sorted[i];
+            const int slot = gbase[r.bin() >> shift] + i;  // neighbouring lanes: neighbouring slots
+            if ((uint32_t)slot >= (uint32_t)cap) {
+                ++bad;
+                continue;
+            }
+            tmp[slot] = r;
         }
         __syncthreads();
     }
+    if (bad) atomicAdd(&scalars[2], bad);
 }
 
 // Level 2.  Work-group w takes the w-th equal share of tmp in chunks of CHUNK records.  tmp is ordered by
@@ -495,72 +458,115 @@ __global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) coarse_scatter_kernel
 // coarse bins, i.e. at most a few hundred bins.  The chunk is counting-sorted by bin in LDS exactly as level 1 sorts
 // by coarse bin, each bin's range is reserved with one global atomic, and the records leave as runs.  A chunk that
 // spans more than 1024 bins (very sparse regions) falls back to one global atomic per record.
-// `tmp` is ordered by (bin >> in_shift); this level orders by key = bin >> kshift (kshift < in_shift; 0 = the final
-// level), writing key k's records to [bin_start[k << kshift], ...) of `out`, with `cursor` (one entry per key,
-// zeroed) handing out the ranges.
-template <int NT, int CHUNK>
-__global__ void __launch_bounds__(NT, (NT == 512 ? 8 : 4)) fine_scatter_kernel(Geom g, const int32_t *__restrict__ bin_start,
-                                                          int32_t *__restrict__ cursor, int in_shift, int kshift,
-                                                          const VisRec *__restrict__ tmp, VisRec *__restrict__ out)
+template <int NT, int CHUNK, bool T12>
+__global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32_t *__restrict__ bin_start,
+                                                             int32_t *__restrict__ cursor, int shift,
+                                                             const TmpRec<T12> *__restrict__ tmp,
+                                                             VisRec *__restrict__ out, int32_t cap,
+                                                             int32_t *__restrict__ scalars)
 {
     extern __shared__ int32_t smem[];
-    VisRec *sorted = reinterpret_cast<VisRec *>(smem);  // [CHUNK]
-    int32_t *hist = smem + CHUNK * 4;                   // [1024]
-    int32_t *gbase = hist + 1024;                       // [1024]
-    int32_t *wtot = gbase + 1024;                       // [17]
+    TmpRec<T12> *sorted = reinterpret_cast<TmpRec<T12> *>(smem);  // [CHUNK]
+    int32_t *hist = smem + CHUNK * (sizeof(TmpRec<T12>) / 4);     // [1024]
+    int32_t *gbase = hist + 1024;                                 // [1024]
+    int32_t *wtot = gbase + 1024;                                 // [17]
     const int tid = threadIdx.x;
     constexpr int PER = CHUNK / NT;
-    if (LIGHT_PRIO && NT == 512) __builtin_amdgcn_s_setprio(LIGHT_PRIO);  // beside a tile kernel: see bin_count_kernel
-    const int64_t ntot = bin_start[g.nbins];
+    int64_t ntot = bin_start[g.nbins];
+    if (ntot > cap) ntot = cap;  // (level 1 has written nothing beyond `cap`)
     int64_t per = (ntot + gridDim.x - 1) / gridDim.x;
     per = (per + CHUNK - 1) / CHUNK * CHUNK;
     const int64_t lo = min((int64_t)blockIdx.x * per, ntot), hi = min(lo + per, ntot);
-    const int up = in_shift - kshift;
+    int bad = 0;
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         const int64_t c1 = min(c0 + CHUNK, hi);
-        const int cb_first = tmp[c0].pad >> in_shift, cb_last = tmp[c1 - 1].pad >> in_shift;
-        const int k0 = cb_first << up, span = (cb_last - cb_first + 1) << up;  // keys k0 .. k0 + span
+        int b_first = tmp[c0].bin(), b_last = tmp[c1 - 1].bin();
+        b_first = min(max(b_first, 0), g.nbins - 1);
+        b_last = min(max(b_last, b_first), g.nbins - 1);
+        const int k0 = (b_first >> shift) << shift, span = (((b_last >> shift) + 1) << shift) - k0;  // bins k0 .. k0 + span
         if (span > 1024) {  // rare: one global atomic per record
             for (int64_t i = c0 + tid; i < c1; i += NT) {
-                const int4 r = *reinterpret_cast<const int4 *>(tmp + i);
-                const int k = r.w >> kshift;
-                const int slot = bin_start[k << kshift] + atomicAdd(&cursor[k], 1);
-                *reinterpret_cast<int4 *>(out + slot) = r;
+                const TmpRec<T12> r = tmp[i];
+                const int k = r.bin();
+                if ((uint32_t)k >= (uint32_t)g.nbins) {
+                    ++bad;
+                    continue;
+                }
+                const int slot = bin_start[k] + atomicAdd(&cursor[k], 1);
+                if ((uint32_t)slot >= (uint32_t)cap) {
+                    ++bad;
+                    continue;
+                }
+                out[slot] = r.final_rec();
             }
             continue;
         }
         for (int i = tid; i < span; i += NT) hist[i] = 0;
         __syncthreads();
-        int4 r[PER];
-        int rank[PER];
+        TmpRec<T12> r[PER];
+        int key[PER], rank[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int64_t i = c0 + q * NT + tid;
-            r[q] = make_int4(0, 0, 0, -1);
-            if (i < c1) r[q] = NT == 512 ? ld_nt(reinterpret_cast<const int4 *>(tmp + i)) : *reinterpret_cast<const int4 *>(tmp + i);
+            key[q] = -1;
+            if (i < c1) {
+                r[q] = tmp[i];
+                key[q] = r[q].bin() - k0;
+                if ((uint32_t)key[q] >= (uint32_t)span || k0 + key[q] >= g.nbins) {  // tmp not ordered (cannot happen)
+                    key[q] = -1;
+                    ++bad;
+                }
+            }
         }
 #pragma unroll
-        for (int q = 0; q < PER; ++q) rank[q] = r[q].w >= 0 ? atomicAdd(&hist[(r[q].w >> kshift) - k0], 1) : 0;
+        for (int q = 0; q < PER; ++q) rank[q] = key[q] >= 0 ? atomicAdd(&hist[key[q]], 1) : 0;
         __syncthreads();
         scan_entries<NT>(hist, span, wtot, [&](int e, int c, int base) {
-            gbase[e] = bin_start[(k0 + e) << kshift] + atomicAdd(&cursor[k0 + e], c) - base;
+            gbase[e] = bin_start[k0 + e] + atomicAdd(&cursor[k0 + e], c) - base;
         });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-            if (r[q].w >= 0) *reinterpret_cast<int4 *>(sorted + hist[(r[q].w >> kshift) - k0] + rank[q]) = r[q];
+            if (key[q] >= 0) sorted[hist[key[q]] + rank[q]] = r[q];
         __syncthreads();
-        const int total = (int)(c1 - c0);
+        const int total = wtot[16];
         for (int i = tid; i < total; i += NT) {
-            const int4 x = *reinterpret_cast<const int4 *>(sorted + i);
-            int4 *dst = reinterpret_cast<int4 *>(out + gbase[(x.w >> kshift) - k0] + i);
-            if (NT == 512)
-                st_nt(dst, x);
-            else
-                *dst = x;
+            const TmpRec<T12> x = sorted[i];
+            const int slot = gbase[x.bin() - k0] + i;
+            if ((uint32_t)slot >= (uint32_t)cap) {
+                ++bad;
+                continue;
+            }
+            out[slot] = x.final_rec();
         }
         __syncthreads();
     }
+    if (bad) atomicAdd(&scalars[2], bad);
+}
+
+template <bool FROM_PRE, bool T12>
+static int launch_two_level(gridhip_ctx *ctx, const Geom &g, const Tables &t, int64_t n, const double *u, const double *v,
+                            int64_t uv_stride, const int64_t *wbin, int shift, int ncoarse, int cblocks,
+                            const unsigned long long *pre, PreFmt pf, int32_t cap)
+{
+    constexpr int CHUNK = 8192;
+    const size_t coarse_lds = (size_t)CHUNK * sizeof(TmpRec<T12>) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
+    const size_t fine_lds = (size_t)CHUNK * sizeof(TmpRec<T12>) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
+    auto coarse = coarse_scatter_kernel<1024, CHUNK, FROM_PRE, T12>;
+    auto fine = fine_scatter_kernel<1024, CHUNK, T12>;
+    const uint32_t bit = 2u << ((FROM_PRE ? 1 : 0) + (T12 ? 2 : 0));
+    if (!(ctx->attr_mask & bit)) {
+        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+        ctx->attr_mask |= bit;
+    }
+    int32_t *ccur = (int32_t *)ctx->blockhist.ptr;
+    TmpRec<T12> *tmp = (TmpRec<T12> *)ctx->recs_tmp.ptr;
+    hipLaunchKernelGGL(coarse, dim3(cblocks), dim3(1024), coarse_lds, ctx->stream, g, n, u, v, uv_stride, wbin, t.bin_start,
+                       ccur, shift, ncoarse, tmp, pre, pf, cap, t.scalars);
+    hipLaunchKernelGGL(fine, dim3(cblocks), dim3(1024), fine_lds, ctx->stream, g, t.bin_start, t.cursor, shift,
+                       (const TmpRec<T12> *)tmp, (VisRec *)ctx->recs.ptr, cap, t.scalars);
+    return GRIDHIP_OK;
 }
 
 int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
@@ -571,119 +577,78 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     Tables t = tables_of(ctx, g);
     int32_t *block_hist = nullptr;
     GH_CHECK_HIP(ctx, hipMemsetAsync(t.bin_count, 0, (size_t)g.nbins * sizeof(int32_t), ctx->stream));
-    if (!ctx->pre_light) {
-        ctx->bin_scalars = ctx->d_scalars;
-        ctx->main_binned = true;  // (a later pipelined pre-pass shares recs_tmp / blockhist with this one)
-    }
-    t.scalars = ctx->bin_scalars;  // [0] = dropped (wbin out of range)
-    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars, 0, 16 * sizeof(int32_t), ctx->stream));
+    // [0] = dropped (wbin out of range), [2] = errors; ([1] belongs to the aw gridders, which bin in batches)
+    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars, 0, sizeof(int32_t), ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 2, 0, sizeof(int32_t), ctx->stream));
+    // record slots the scatter may write: all n of them - or fewer under the test hook "fault_inject", which
+    // hides the array's last slots so that the bounds checks have something to catch
+    const int64_t cap64 = n - (ctx->opt.fault_inject > 0 ? ctx->opt.fault_inject : 0);
+    const int32_t cap = (int32_t)(cap64 < 0 ? 0 : cap64);
 
     // The histogram of one launch lives in LDS; when there are more bins than fit (large grids x 8
-    // w-groups) the bins are covered in several windows, each a full sweep of the stream.  Beyond 8
-    // windows the re-reads cost more than plain global atomics.
-    // `light`: this pre-pass runs beside a tile kernel (async_prepass): 512-thread work-groups with at most
-    // 40 KB of LDS, whatever that costs in extra sweeps - it has the tile kernel's whole duration.
-    const bool light = ctx->pre_light;
-    const int cap = light ? 10240 : (int)(((size_t)ctx->max_lds - 8192) / sizeof(int32_t));
-    const int windows = (g.nbins + cap - 1) / cap;
-    const bool lds_hist = (windows <= 8 || light) && ctx->opt.prepass != 3;  // prepass = 3: global atomics, no LDS
+    // w-groups) the bins are covered in several windows.  Beyond 8 windows the re-reads cost more than plain
+    // global atomics.
+    const int lds_cap = (int)(((size_t)ctx->max_lds - 8192) / sizeof(int32_t));
+    const int windows = (g.nbins + lds_cap - 1) / lds_cap;
+    const int64_t p = ctx->opt.prepass;
+    const bool lds_hist = windows <= 8 && p != 3;  // prepass = 3: global atomics, no LDS
     const int win = lds_hist ? (g.nbins + windows - 1) / windows : g.nbins;
     const size_t hist_bytes = (size_t)win * sizeof(int32_t);
-    const int threads = light ? 512 : ctx->opt.prepass == 3 ? 256 : 1024;
+    const int threads = p == 3 ? 256 : 1024;
     // one block per CU with an LDS histogram; more, smaller slices when counting in global memory
-    int blocks = lds_hist ? ctx->num_cu * (hist_bytes <= 64 * 1024 && !light ? 2 : 1) : ctx->num_cu * 8;
+    int blocks = lds_hist ? ctx->num_cu * (hist_bytes <= 64 * 1024 ? 2 : 1) : ctx->num_cu * 8;
     // at least 16 K visibilities per work-group: below that the per-work-group histogram traffic
     // (and the serial walk over work-groups in bin_offsets_kernel) outweighs the parallelism
     int64_t need = (n + 16383) / 16384;
     if (need < 1) need = 1;
     if (blocks > need) blocks = (int)need;
+    if (lds_hist && !(ctx->attr_mask & 1u)) {
+        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_scatter_kernel<true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+        ctx->attr_mask |= 1u;
+    }
 
     // two-level scatter for large streams (only the counting sweep needs the histogram windows)
-    int shift = light ? 8 : 6;  // beside a tile kernel: fewer, longer runs per level and one level more
+    int shift = 6;
     while (((g.nbins + (1 << shift) - 1) >> shift) > 1024) ++shift;
     const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
-    const bool two_level =
-        lds_hist && (light || ctx->opt.prepass == 2 || (ctx->opt.prepass == 0 && n >= ((int64_t)1 << 22)));
+    const bool two_level = lds_hist && (p == 2 || p == 4 || p == 5 || (p == 0 && n >= ((int64_t)1 << 22)));
     if (two_level) {
-        GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
-        // coarse cursors; beside a tile kernel also every work-group's slots per coarse bin
-        GH_CHECK(ws_reserve(ctx, ctx->blockhist,
-                            ((size_t)(light ? ctx->num_cu * 2 + 1 : 1) * ncoarse + (light ? (size_t)g.nbins + 64 : 0)) *
-                                sizeof(int32_t)));
-        int32_t *ccur = (int32_t *)ctx->blockhist.ptr;
-        VisRec *tmp = (VisRec *)ctx->recs_tmp.ptr;
-        if (!(ctx->attr_mask & 2u)) {
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse_scatter_kernel<1024, 8192>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine_scatter_kernel<1024, 8192>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            ctx->attr_mask |= 2u;
-        }
-        GH_CHECK_HIP(ctx, hipMemsetAsync(ccur, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
-        const int chunk = light ? 2048 : 8192;
-        const size_t coarse_lds = (size_t)chunk * sizeof(VisRec) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
-        const size_t fine_lds = (size_t)chunk * sizeof(VisRec) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
-        int cblocks = light ? ctx->num_cu * 2 : ctx->num_cu;  // (8192-record chunks: one work-group per CU)
-        int64_t cneed = (n + 4 * chunk - 1) / (4 * chunk);
+        const bool t12 = g.nbins <= TMP12_MAX_BINS && g.T <= 128 && p != 5;
+        GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * (t12 ? 12 : 16)));
+        GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));  // coarse cursors
+        GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->blockhist.ptr, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
+        int cblocks = ctx->num_cu;  // (8192-record chunks: one work-group per CU)
+        int64_t cneed = (n + 4 * 8192 - 1) / (4 * 8192);
         if (cblocks > cneed) cblocks = (int)(cneed < 1 ? 1 : cneed);
-        if (light) {
-            GH_CHECK(ws_reserve(ctx, ctx->recs_raw, (size_t)(n > 0 ? n : 1) * (sizeof(VisRec) + sizeof(int32_t)) + 256));
-            VisRec *raw = (VisRec *)ctx->recs_raw.ptr;
-            int32_t *bins = (int32_t *)(raw + (n > 0 ? n : 1));
-            int sblocks = ctx->num_cu * 2;
-            if (sblocks > need) sblocks = (int)need;
-            hipLaunchKernelGGL(light_records_kernel, dim3(sblocks), dim3(512), 0, ctx->stream, g, n, u, v, uv_stride,
-                               wbin, raw, bins, t.scalars);
-            for (int wdw = 0; wdw < windows; ++wdw) {
-                const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
-                hipLaunchKernelGGL(light_count_kernel, dim3(blocks), dim3(512), hist_bytes, ctx->stream, n, bins,
-                                   t.bin_count, b_lo, b_hi);
-            }
-            hipLaunchKernelGGL(bin_scan_kernel<512>, dim3(1), dim3(512), 0, ctx->stream, g, t.bin_count, t.bin_start,
-                               t.work_start, t.cursor);
-            // every work-group's slots per coarse bin, fixed beforehand (no reservations at run time)
-            int32_t *woff = (int32_t *)ctx->blockhist.ptr + ncoarse;
-            hipLaunchKernelGGL(light_coarse_count_kernel, dim3(cblocks), dim3(512), (size_t)ncoarse * sizeof(int32_t),
-                               ctx->stream, n, bins, shift, ncoarse, woff);
-            hipLaunchKernelGGL(light_coarse_offsets_kernel, dim3((ncoarse + 255) / 256), dim3(256), 0, ctx->stream,
-                               ncoarse, cblocks, shift, t.bin_start, woff);
-            hipLaunchKernelGGL((coarse_scatter_kernel<512, 2048, true>), dim3(cblocks), dim3(512),
-                               coarse_lds + (size_t)ncoarse * sizeof(int32_t), ctx->stream, g, n, u, v, uv_stride, wbin,
-                               t.bin_start, ccur, shift, ncoarse, tmp, raw, woff);
-            // runs shorter than 128 B are what slows a tile kernel next door (tools/coresidency_probe.py), so the
-            // levels below the coarse one go in steps of 16 keys: with 2 048-record chunks every run is >= 1 KB
-            const VisRec *src = tmp;
-            VisRec *spare = raw;  // (its records have been consumed by the coarse level)
-            for (int in_shift = shift; in_shift > 0;) {
-                const int kshift = in_shift > 4 ? in_shift - 4 : 0;
-                VisRec *dst = kshift == 0 ? (VisRec *)ctx->recs.ptr : spare;
-                int32_t *cur = t.cursor;
-                if (kshift > 0) {  // cursors of an intermediate level: behind the work-group offsets
-                    cur = (int32_t *)ctx->blockhist.ptr + (size_t)(ctx->num_cu * 2 + 1) * ncoarse;
-                    GH_CHECK_HIP(ctx, hipMemsetAsync(cur, 0, (size_t)((g.nbins >> kshift) + 1) * sizeof(int32_t), ctx->stream));
-                }
-                hipLaunchKernelGGL((fine_scatter_kernel<512, 2048>), dim3(cblocks), dim3(512), fine_lds, ctx->stream, g,
-                                   t.bin_start, cur, in_shift, kshift, src, dst);
-                spare = const_cast<VisRec *>(src);
-                src = dst;
-                in_shift = kshift;
-            }
-        } else {
-            for (int wdw = 0; wdw < windows; ++wdw) {
-                const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
-                hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
-                                   v, uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi);
-            }
-            hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
-                               t.work_start, t.cursor);
-            hipLaunchKernelGGL((coarse_scatter_kernel<1024, 8192>), dim3(cblocks), dim3(1024), coarse_lds, ctx->stream,
-                               g, n, u, v, uv_stride, wbin, t.bin_start, ccur, shift, ncoarse, tmp, (const VisRec *)nullptr,
-                               (const int32_t *)nullptr);
-            hipLaunchKernelGGL((fine_scatter_kernel<1024, 8192>), dim3(cblocks), dim3(1024), fine_lds, ctx->stream, g,
-                               t.bin_start, t.cursor, shift, 0, tmp, (VisRec *)ctx->recs.ptr);
+        // pre-records: when bin | lx | ly | kslice fit one 64-bit word
+        const int bb = bits_for(g.nbins);
+        const int64_t nslices = g.per_vis ? (n > 0 ? n : 1) : (int64_t)g.W * g.Q * g.Q;
+        const bool use_pre = p != 4 && g.T <= 128 && bb + 14 + bits_for(nslices) <= 63;
+        unsigned long long *pre = nullptr;
+        if (use_pre) {
+            GH_CHECK(ws_reserve(ctx, ctx->recs_raw, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
+            pre = (unsigned long long *)ctx->recs_raw.ptr;
         }
+        for (int wdw = 0; wdw < windows; ++wdw) {
+            const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
+            hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
+                               uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
+                               PreFmt{wdw == 0 ? bb : -bb}, pre);
+        }
+        hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
+                           t.work_start, t.cursor);
+        const PreFmt pf{bb};
+        if (use_pre && t12)
+            GH_CHECK((launch_two_level<true, true>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
+        else if (use_pre)
+            GH_CHECK((launch_two_level<true, false>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
+        else if (t12)
+            GH_CHECK((launch_two_level<false, true>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
+        else
+            GH_CHECK((launch_two_level<false, false>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
         GH_CHECK_HIP(ctx, hipGetLastError());
         return GRIDHIP_OK;
     }
@@ -691,21 +656,16 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     if (lds_hist) {
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)blocks * g.nbins * sizeof(int32_t)));
         block_hist = (int32_t *)ctx->blockhist.ptr;
-        if (!(ctx->attr_mask & 1u)) {
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_scatter_kernel<true>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
-            ctx->attr_mask |= 1u;
-        }
         for (int wdw = 0; wdw < windows; ++wdw) {
             const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
             hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
-                               v, uv_stride, wbin, t.bin_count, block_hist, t.scalars, b_lo, b_hi);
+                               v, uv_stride, wbin, t.bin_count, block_hist, t.scalars, b_lo, b_hi, PreFmt{0},
+                               (unsigned long long *)nullptr);
         }
     } else {
         hipLaunchKernelGGL(bin_count_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_count, block_hist, t.scalars, 0, g.nbins);
+                           uv_stride, wbin, t.bin_count, block_hist, t.scalars, 0, g.nbins, PreFmt{0},
+                           (unsigned long long *)nullptr);
     }
     hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                        t.work_start, t.cursor);
@@ -716,11 +676,12 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
             hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n,
                                u, v, uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr,
-                               b_lo, b_hi);
+                               b_lo, b_hi, cap, t.scalars);
         }
     } else
         hipLaunchKernelGGL(bin_scatter_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr, 0, g.nbins);
+                           uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr, 0, g.nbins,
+                           cap, t.scalars);
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }

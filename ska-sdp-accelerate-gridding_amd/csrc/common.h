@@ -11,17 +11,15 @@
 namespace gridhip {
 
 // One visibility after the binning pre-pass: where its footprint starts inside the tile, which
-// kernel slice it uses and where its value lives in the caller's array.  16 B, so a wave
-// fetches it with one scalar load (s_load_dwordx4) and the pre-pass writes it with one store.
+// kernel slice it uses and where its value lives in the caller's array.  12 B: one dwordx3 access.
 // Records do not depend on the visibility values: the image and PSF passes of do_imaging
 // (src/Gridding.hs:538,541) can share one binning.
-struct __attribute__((aligned(16))) VisRec {
+struct VisRec {
     int32_t lxy;     // ly0 << 16 | lx0 : footprint origin relative to the tile's LDS region
     int32_t kslice;  // (wbin*Q + yf)*Q + xf : which [gh][gw] kernel slice
     int32_t orig;    // index in the caller's arrays (vis is gathered from / degrid writes there)
-    int32_t pad;
 };
-static_assert(sizeof(VisRec) == 16, "VisRec must be 16 bytes");
+static_assert(sizeof(VisRec) == 12, "VisRec must be 12 bytes");
 
 // Geometry of one gridding call, shared by host and device code.
 struct Geom {
@@ -39,10 +37,12 @@ struct Geom {
     int32_t chunk;        // max visibilities per work item
     int32_t dbg;          // ablation switch for tuning runs (0 = off)
     int32_t per_vis;      // 1: the kernel table holds one [gh][gw] slice per visibility (aw gridders)
+    int32_t nvis;         // visibilities of the call: a record's `orig` is below it
+    int32_t nslices;      // [gh][gw] slices in the kernel table: a record's `kslice` is below it
 };
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, async_prepass = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1;
 };
 
 struct Workspace {
@@ -63,25 +63,11 @@ struct gridhip_ctx {
     gridhip::Workspace tables;  // bin_count / bin_start / work_start / cursors / scalars
     gridhip::Workspace stage;   // staging for the host-pointer entry points
     gridhip::Workspace sorted;  // sorted-list scratch of the tap-reusing tile kernel (tile_sorted.hip)
-    gridhip::Workspace recs_raw;   // unbinned records + bin numbers of a pre-pass that runs beside a tile kernel (bin.hip)
+    gridhip::Workspace recs_raw;   // 8-byte pre-records the counting sweep leaves for the scatter (bin.hip)
     gridhip::Workspace recs_tmp;   // coarse-binned records between the two scatter levels of the pre-pass (bin.hip)
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
     int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=aw drops, [2]=errors, [4..19] work queues,
                                    // [20..27] clock stamps of the last sorted tile kernel, [32..] profile
-    int32_t *bin_scalars = nullptr;  // where the pre-pass counts (d_scalars, or a pipeline buffer's own 16 ints)
-    bool pre_light = false;  // the pre-pass being launched runs beside a tile kernel (bin.hip)
-    // async_prepass: a call's pre-pass runs on pre_stream into one of two record/table sets while the previous
-    // call's tile kernel (main stream) still reads the other (api.hip)
-    struct PipeBuf {
-        gridhip::Workspace recs, tables;
-        hipEvent_t pre_done = nullptr, tile_done = nullptr;
-        bool used = false;
-    } pipe[2];
-    hipStream_t pre_stream = nullptr;
-    int32_t *pipe_scalars = nullptr;  // 2 x 16 ints
-    int pipe_idx = 0;
-    hipEvent_t pipe_order = nullptr;
-    bool main_binned = false;  // a pre-pass ran on the main stream since the last pipelined call (shared scratch)
     int num_cu = 256;
     int max_lds = 160 * 1024;
     bool timing = false;

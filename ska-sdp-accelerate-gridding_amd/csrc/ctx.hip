@@ -87,6 +87,8 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->Q = (int32_t)Q;
     g->gh = (int32_t)gh;
     g->gw = (int32_t)gw;
+    g->nvis = (int32_t)(n > 0 ? n : 1);
+    g->nslices = (int32_t)(W * Q * Q);
 
     const size_t lds_cap = (size_t)ctx->max_lds - 1024;
     int T = (int)ctx->opt.tile;
@@ -219,7 +221,6 @@ int gridhip_create(int device, gridhip_ctx **out)
         gridhip_destroy(ctx);
         return GRIDHIP_ENOMEM;
     }
-    ctx->bin_scalars = ctx->d_scalars;
     for (int i = 0; i < gridhip_ctx::EV_RING * 3; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
             gridhip_destroy(ctx);
@@ -235,20 +236,12 @@ int gridhip_destroy(gridhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     fft_release(ctx);
-    Workspace *all[] = {&ctx->recs,     &ctx->tables,       &ctx->stage,          &ctx->blockhist,     &ctx->sorted,
-                        &ctx->recs_tmp, &ctx->recs_raw, &ctx->pipe[0].recs, &ctx->pipe[0].tables, &ctx->pipe[1].recs, &ctx->pipe[1].tables};
+    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp, &ctx->recs_raw};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     for (int i = 0; i < gridhip_ctx::EV_RING * 3; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    for (auto &pb : ctx->pipe) {
-        if (pb.pre_done) (void)hipEventDestroy(pb.pre_done);
-        if (pb.tile_done) (void)hipEventDestroy(pb.tile_done);
-    }
-    if (ctx->pipe_order) (void)hipEventDestroy(ctx->pipe_order);
-    if (ctx->pipe_scalars) (void)hipFree(ctx->pipe_scalars);
-    if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GRIDHIP_OK;
@@ -292,7 +285,8 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "sort")) return &ctx->opt.sort;
     if (!strcmp(key, "dbg")) return &ctx->opt.dbg;
     if (!strcmp(key, "prepass")) return &ctx->opt.prepass;
-    if (!strcmp(key, "async_prepass")) return &ctx->opt.async_prepass;
+    if (!strcmp(key, "fault_inject")) return &ctx->opt.fault_inject;
+    if (!strcmp(key, "aw_cache")) return &ctx->opt.aw_cache;
     return nullptr;
 }
 
@@ -431,8 +425,7 @@ int gridhip_last_dropped(gridhip_ctx *ctx, int64_t *dropped)
     *dropped = 0;
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     int32_t h = 0;
-    // (a pipelined call's pre-pass ran on the side stream, but its tile kernel on ctx->stream waited for it)
-    GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->bin_scalars, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_scalars, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *dropped = h;
     return GRIDHIP_OK;

@@ -87,7 +87,6 @@ int launch_direct_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
                        int64_t gh, int64_t gw, const double *gcf, const double *u, const double *v,
                        int64_t uv_stride, const int64_t *wbin, const double *vis)
 {
-    ctx->bin_scalars = ctx->d_scalars;
     GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16 * sizeof(int32_t), ctx->stream));
     if (n <= 0) return GRIDHIP_OK;
     int64_t blocks = (n + 3) / 4;  // 4 waves per block, one visibility per wave step

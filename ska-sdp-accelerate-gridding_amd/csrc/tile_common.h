@@ -39,17 +39,22 @@ __device__ __forceinline__ bool find_work(const Geom &g, const int32_t *__restri
     return find_work_at(g, bin_start, work_start, blockIdx.x % g.ngroups, blockIdx.x / g.ngroups, w);
 }
 
-// All lanes of the wave read the same 16 bytes (one broadcast transaction).  Vector loads on
-// purpose: scalar loads share the lgkmcnt counter with the LDS atomics and would make every
+// All lanes of the wave read the same 12 bytes (one broadcast transaction), or consecutive records (coalesced).
+// Vector loads on purpose: scalar loads share the lgkmcnt counter with the LDS atomics and would make every
 // record fetch wait for the wave's outstanding ds_add_f64s.
-__device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int idx)
+// Nothing read from a record becomes an address before it has been brought into range: a record slot the pre-pass
+// never wrote (only possible when the caller's arrays change between its sweeps) holds stale bytes, and those may
+// cost a wrong sum but never a wild access.
+__device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int idx, const Geom &g, bool *clamped = nullptr)
 {
-    const int4 a = *reinterpret_cast<const int4 *>(recs + idx);
+    const int32_t *p = reinterpret_cast<const int32_t *>(recs + idx);
+    const int32_t a = p[0], k = p[1], o = p[2];
     VisRec r;
-    r.lxy = a.x;
-    r.kslice = a.y;
-    r.orig = a.z;
-    r.pad = 0;
+    const int32_t lx = min(a & 0xffff, g.T - 1), ly = min((a >> 16) & 0xffff, g.T - 1);
+    r.lxy = (ly << 16) | lx;
+    r.kslice = min(max(k, 0), g.nslices - 1);
+    r.orig = min(max(o, 0), g.nvis - 1);
+    if (clamped) *clamped = r.lxy != a || r.kslice != k || r.orig != o;
     return r;
 }
 

@@ -60,14 +60,14 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
         // Per-lane LDS offsets of this lane's taps.  The loop below is branch-free: a lane
         // without a tap in the last step (lane >= TAIL) reads tap 0 (valid memory) and adds 0.0
         // to the cell of tap lane-32, which sits on a bank pair none of the step's real taps
-        // use.  (A divergent tail block would hide its s_waitcnt from the other path and make
+        // use (tails of 32 taps or fewer: to one of the tail's own cells).  (A divergent tail block would hide its s_waitcnt from the other path and make
         // the compiler drain every outstanding load at the loop head.)
         int loff[NSTEP];
         const bool tail_ok = lane < TAIL || TAIL == 64;
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             int t = s * 64 + lane;
-            if (s == NSTEP - 1 && !tail_ok) t = lane - 32;
+            if (s == NSTEP - 1 && !tail_ok) t = TAIL > 32 ? lane - 32 : lane % TAIL;  // (a cell of the footprint)
             loff[s] = (t / S) * g.ldw + (t % S);
         }
         const int ttail = tail_ok ? (NSTEP - 1) * 64 + lane : 0;
@@ -109,16 +109,16 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
             // test and the pipeline collapses.  The odd one out at the end is a repeat of the
             // last visibility with its value forced to zero (adds 0.0 to the same cells).
             double2 kA[NSTEP], kB[NSTEP], valA, valB;
-            VisRec r0 = load_rec(recs, vi);                   // visibility t
-            VisRec r1 = load_rec(recs, min(vi + nw, last));   // t+1
+            VisRec r0 = load_rec(recs, vi, g);                   // visibility t
+            VisRec r1 = load_rec(recs, min(vi + nw, last), g);   // t+1
             issue(r0, valA, kA);
             for (; vi <= last; vi += 2 * nw) {
-                const VisRec r2 = load_rec(recs, min(vi + 2 * nw, last));  // t+2
+                const VisRec r2 = load_rec(recs, min(vi + 2 * nw, last), g);  // t+2
                 issue(r1, valB, kB);
                 __builtin_amdgcn_sched_barrier(0);
                 accum(r0, valA, kA);
                 __builtin_amdgcn_sched_barrier(0);
-                const VisRec r3 = load_rec(recs, min(vi + 3 * nw, last));  // t+3
+                const VisRec r3 = load_rec(recs, min(vi + 3 * nw, last), g);  // t+3
                 issue(r2, valA, kA);
                 __builtin_amdgcn_sched_barrier(0);
                 if (vi + nw > last) valB = make_double2(0.0, 0.0);
@@ -137,12 +137,12 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
         const int last = w.v_hi - 1;
         int vi = w.v_lo + wave;
         if (vi <= last) {
-            VisRec r = load_rec(recs, vi);
-            VisRec rn = load_rec(recs, min(vi + nw, last));
+            VisRec r = load_rec(recs, vi, g);
+            VisRec rn = load_rec(recs, min(vi + nw, last), g);
             double2 val = vis[r.orig];
             double2 kv_next = gcf[(size_t)r.kslice * S2 + min(lane, S2 - 1)];
             for (; vi <= last; vi += nw) {
-                const VisRec rnn = load_rec(recs, min(vi + 2 * nw, last));
+                const VisRec rnn = load_rec(recs, min(vi + 2 * nw, last), g);
                 const double2 valn = vis[rn.orig];
                 const double2 *kp = gcf + (size_t)r.kslice * S2;
                 const double2 *kpn = gcf + (size_t)rn.kslice * S2;
@@ -231,11 +231,11 @@ __global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec 
     const int last = w.v_hi - 1;
     int vi = w.v_lo + wave;
     if (vi <= last) {
-        VisRec r = load_rec(recs, vi);
-        VisRec rn = load_rec(recs, min(vi + nw, last));
+        VisRec r = load_rec(recs, vi, g);
+        VisRec rn = load_rec(recs, min(vi + nw, last), g);
         double2 kv_next = gcf[(size_t)r.kslice * S2 + min(lane, S2 - 1)];
         for (; vi <= last; vi += nw) {
-            const VisRec rnn = load_rec(recs, min(vi + 2 * nw, last));
+            const VisRec rnn = load_rec(recs, min(vi + 2 * nw, last), g);
             const double2 *kp = gcf + (size_t)r.kslice * S2;
             const double2 *kpn = gcf + (size_t)rn.kslice * S2;
             const int lbase = (r.lxy >> 16) * g.ldw + (r.lxy & 0xffff);

@@ -150,7 +150,11 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
         for (int r0 = lane; r0 < cnt; r0 += 8 * 64) {
             int key[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) key[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1)).kslice - first_slice;
+            for (int q = 0; q < 8; ++q) {
+                bool off;  // (a stale record is counted by neither pass)
+                key[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1), g, &off).kslice - first_slice;
+                if (off) key[q] = -1;
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (r0 + q * 64 < cnt && (unsigned)key[q] < (unsigned)nkeys) atomicAdd(&hist[key[q]], 1);
@@ -185,8 +189,9 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
         for (int r0 = lane; r0 < cnt; r0 += 8 * 64) {
             VisRec rec[8];
             double2 val[8];
+            bool off[8];  // a field of the record was out of range (stale slot): not staged, counted
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rec[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1));
+            for (int q = 0; q < 8; ++q) rec[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1), g, &off[q]);
             if (!DEGRID) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) val[q] = (ABL & 8) ? make_double2(1.0, (double)q) : vis[rec[q].orig];
@@ -195,7 +200,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             for (int q = 0; q < 8; ++q) {
                 if (r0 + q * 64 >= cnt) break;
                 const int key = rec[q].kslice - first_slice;
-                if ((unsigned)key >= (unsigned)nkeys) {  // cannot happen unless binning and kernel disagree
+                if (off[q] || (unsigned)key >= (unsigned)nkeys) {  // cannot happen unless binning and kernel disagree
                     ++bad;
                     continue;
                 }

@@ -104,12 +104,15 @@ def test_sorted_variant_matches_oracle(ctx, oracle, dist):
                                    (1024, 1024, 8, 2, 7, 7, 200000, {"tile": 16, "wgroups": 8}),  # 34 848 bins: 35 per coarse bin
                                    (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 32, "wgroups": 8}),
                                    (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 16, "wgroups": 8}),  # 4 counting windows, 136 coarse-bin width
+                                   (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 8, "wgroups": 4}),  # 264 196 bins > 2^18: 16-byte intermediate records
                                    (64, 64, 1, 1, 1, 1, 1000, {}), (200, 200, 2, 2, 31, 31, 2000, {})])
-@pytest.mark.parametrize("dist", ["uniform", "core"])
-def test_two_level_prepass(ctx, oracle, shape, dist):
+@pytest.mark.parametrize("dist,mode", [("uniform", 2), ("core", 2), ("uniform", 4), ("core", 5)])
+def test_two_level_prepass(ctx, oracle, shape, dist, mode):
     """The scatter of the binning pre-pass in two levels (LDS-sorted runs into coarse bins, then to the bins):
     automatic from 2^22 visibilities, forced here on small streams.  Coordinates spill over the grid edges
-    (dropped visibilities leave holes in neither level) and some wbins are out of range."""
+    (dropped visibilities leave holes in neither level) and some wbins are out of range.
+    mode 2: the scatter reads the counting sweep's 8-byte pre-records and moves 12-byte records; 4: it recomputes
+    from the stream; 5: 16-byte intermediate records."""
     N, M, W, Q, gh, gw, n, opts = shape
     gcf, u, v, wb, vis = case(1234 + N, N, M, W, Q, gh, gw, n, spread=0.6, dist=dist)
     wb = wb.copy()
@@ -118,11 +121,12 @@ def test_two_level_prepass(ctx, oracle, shape, dist):
     keep = (wb >= 0) & (wb < W)
     ref = oracle.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), u[keep], v[keep], wb[keep], vis[keep], mt_mode=1)
     try:
-        ctx.set_option("prepass", 2)
+        ctx.set_option("prepass", mode)
         for k, val in opts.items():
             ctx.set_option(k, val)
         got = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
         dropped = ctx.last_dropped()
+        assert ctx.get_option("errors") == 0
         d = ctx.degrid2(gcf, ref, (u, v, None), wb)
         ctx.set_option("prepass", 1)
         ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
@@ -371,51 +375,40 @@ def test_device_path_is_ordered_with_the_callers_stream(ctx):
     assert abs((s1 - G2.sum()).item()) / G2.abs().sum().item() < 1e-12
 
 
-def test_async_prepass_pipelines_consecutive_calls(ctx, oracle):
-    """Option async_prepass: call i+1's pre-pass runs on a side stream beside call i's tile kernel, with two
-    record sets used alternately.  Eight calls over three different input sets are enqueued back to back
-    (device arrays, no synchronisation), with a degrid and an unpipelined gridding call in between (they share
-    the pre-pass temporaries); every grid must match the oracle."""
+@pytest.mark.parametrize("mode,n", [(1, 20000), (2, 200000), (4, 200000), (5, 200000), (3, 20000)])
+def test_record_writes_are_bounded_by_the_array(ctx, oracle, mode, n):
+    """Every record store of the pre-pass is checked against the record array's capacity.  The test hook
+    "fault_inject" hides the last k slots from the scatter (a deliberately short table): nothing is written beyond
+    the shortened array, the rejected records are counted in "errors", the host-pointer call reports the
+    inconsistency as GRIDHIP_EINVAL instead of returning a wrong grid silently - and the GPU does not fault."""
+    import gridhip
     import torch
+    N, W, Q, S = 256, 8, 4, 9
+    gcf, u, v, wb, vis = case(77, N, N, W, Q, S, S, n, spread=0.45)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
     dev = torch.device("cuda:0")
-    N, W, Q, S = 384, 16, 4, 15
     t = lambda a: torch.from_numpy(a).to(dev)
-    sets = []
-    for k, n in enumerate((90000, 140000, 60000)):
-        gcf, u, v, wb, vis = case(500 + k, N, N, W, Q, S, S, n, spread=0.58)
-        ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
-        sets.append((t(gcf), t(u), t(v), t(wb), t(vis), ref, gcf, u, v, wb))
-    torch.cuda.synchronize()
-    order = [0, 1, 2, 1, 0, 2, 2, 1]
-    grids, extra = [], {}
+    hide = 1000
     try:
-        ctx.set_option("sort", 1)
-        ctx.set_option("async_prepass", 2)
-        for i, k in enumerate(order):
-            tg, tu, tv, twb, tvis = sets[k][:5]
-            G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
-            ctx.convgrid2(tg, G, (tu, tv, None), twb, tvis)
-            grids.append(G)
-            if i == 2:  # a degrid on the main stream (its own pre-pass) between pipelined calls
-                extra["d"] = ctx.degrid2(tg, t(sets[k][5]), (tu, tv, None), twb)
-            if i == 4:  # and an unpipelined gridding call
-                ctx.set_option("async_prepass", 0)
-                extra["g"] = torch.zeros((N, N), dtype=torch.complex128, device=dev)
-                ctx.convgrid2(tg, extra["g"], (tu, tv, None), twb, tvis)
-                ctx.set_option("async_prepass", 2)
+        ctx.set_option("prepass", mode)
+        ctx.set_option("fault_inject", hide)
+        G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+        ctx.convgrid2(t(gcf), G, (t(u), t(v), None), t(wb), t(vis))
         torch.cuda.synchronize()
         errors = ctx.get_option("errors")
-        dropped = ctx.last_dropped()
+        with pytest.raises(gridhip.GridHipError) as ei:
+            ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+        ctx.set_option("fault_inject", 0)
+        got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+        clean = ctx.get_option("errors")
     finally:
-        ctx.set_option("sort", 0)
-        ctx.set_option("async_prepass", 0)
-    assert errors == 0 and dropped == 0
-    for G, k in zip(grids, order):
-        assert rel(G.cpu().numpy(), sets[k][5]) < TOL
-    assert rel(extra["g"].cpu().numpy(), sets[order[4]][5]) < TOL
-    k = order[2]
-    dref = oracle.degrid2(sets[k][6], sets[k][5], sets[k][7], sets[k][8], sets[k][9])
-    assert rel(extra["d"].cpu().numpy(), dref) < TOL
+        ctx.set_option("prepass", 0)
+        ctx.set_option("fault_inject", 0)
+    assert errors >= hide             # (the sorted kernel may count the holes it finds as well)
+    assert ei.value.code == gridhip._lib.EINVAL
+    assert clean == 0 and rel(got, ref) < TOL
+    # the faulty run lost records, it did not scribble: its grid is the reference minus some footprints
+    assert np.isfinite(G.cpu().numpy()).all()
 
 
 @pytest.mark.parametrize("N,W,Q,S,n", [(512, 32, 8, 15, 200000), (200, 4, 2, 9, 3000), (128, 2, 2, 6, 4000)])
