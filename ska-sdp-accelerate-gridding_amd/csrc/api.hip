@@ -61,7 +61,103 @@ int check_errors(gridhip_ctx *ctx)
     return GRIDHIP_OK;
 }
 
+
+// kernel table -> zero-padded square parts: out[(slice * P + part)][sub][sub] (Geom, "Sub-footprints")
+__global__ void __launch_bounds__(256) pad_kernels_kernel(Geom g, int64_t nslices, const double2 *__restrict__ in,
+                                                          double2 *__restrict__ out)
+{
+    const int sub = g.gh, S2 = sub * sub;
+    const int64_t total = nslices * g.P * S2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(e % S2);
+        const int64_t sp = e / S2;
+        const int part = (int)(sp % g.P);
+        const int64_t slice = sp / g.P;
+        const int i = (part / g.px) * sub + t / sub, j = (part % g.px) * sub + t % sub;
+        out[e] = (i < g.fgh && j < g.fgw) ? in[(slice * g.fgh + i) * g.fgw + j] : make_double2(0.0, 0.0);
+    }
+}
 }  // namespace
+
+namespace gridhip {
+
+// How a kernel shape the tap-reusing tile kernel has no instantiation for is cut into square parts it has one for:
+// py x px parts of side sub = max(ceil(gh / py), ceil(gw / px)), the fewest parts with sub <= 16.
+static bool choose_parts(int64_t gh, int64_t gw, int *py, int *px, int *sub)
+{
+    const int y = (int)((gh + 15) / 16), x = (int)((gw + 15) / 16);
+    const int sy = (int)((gh + y - 1) / y), sx = (int)((gw + x - 1) / x);
+    int sb = sy > sx ? sy : sx;
+    if (sb < 5) sb = 5;  // (smallest instantiation)
+    if (y * x > 64) return false;
+    *py = y;
+    *px = x;
+    *sub = sb;
+    return true;
+}
+
+int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh, int64_t gw, int64_t n, Prep *p)
+{
+    *p = Prep();
+    p->nrec = n;
+    int rc = make_geom(ctx, H, Wd, W, Q, gh, gw, n, &p->g, &p->block, &p->lds);
+    if (rc == GRIDHIP_OK) {
+        // sort: 0 = auto (on when a work item holds enough visibilities for slices to repeat), 1 = on, 2 = off
+        const bool want = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)p->g.nbins >= 256);
+        p->sorted = want && sorted_plan(ctx, p->g, p->block, &p->nkeys, &p->batch, &p->lds_sorted);
+        // a sorted work item may span several LDS batches; keep it big enough to flush each tile once
+        if (p->sorted) p->g.chunk = p->batch;
+        if (p->sorted || ctx->opt.sort == 2) return GRIDHIP_OK;
+    } else if (rc != GRIDHIP_EUNSUPPORTED || ctx->opt.tile != 0)
+        return rc;
+    // sub-footprints: supports above 16 and non-square kernels as P records of a small square support each
+    int py, px, sub;
+    if (ctx->opt.sort != 2 && (gh != gw || gh > 16 || gh < 5) && choose_parts(gh, gw, &py, &px, &sub) &&
+        n * (int64_t)(py * px) < (int64_t)0x7fffff00 && W * Q * Q * (int64_t)(py * px) < ((int64_t)1 << 30)) {
+        Prep q;
+        const int P = py * px;
+        q.nrec = n * P;
+        if (make_geom(ctx, H, Wd, W, Q, sub, sub, q.nrec, &q.g, &q.block, &q.lds) == GRIDHIP_OK) {
+            q.g.fgh = (int32_t)gh;
+            q.g.fgw = (int32_t)gw;
+            q.g.py = py;
+            q.g.px = px;
+            q.g.P = P;
+            q.g.nvis = (int32_t)(n > 0 ? n : 1);
+            q.g.nslices = (int32_t)(W * Q * Q * P);
+            const bool want = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && q.nrec / (int64_t)q.g.nbins >= 256);
+            q.sorted = want && sorted_plan(ctx, q.g, q.block, &q.nkeys, &q.batch, &q.lds_sorted);
+            if (q.sorted) {
+                q.g.chunk = q.batch;
+                *p = q;
+                return GRIDHIP_OK;
+            }
+        }
+    }
+    if (rc == GRIDHIP_EUNSUPPORTED) {  // support too large for an LDS tile: direct global-atomic scatter
+        p->direct = true;
+        return GRIDHIP_OK;
+    }
+    return rc;
+}
+
+int tile_kernels(gridhip_ctx *ctx, const Prep &p, const double *gcf, const double **out)
+{
+    *out = gcf;
+    if (p.g.P == 1 && p.g.fgh == p.g.gh && p.g.fgw == p.g.gw) return GRIDHIP_OK;
+    const int64_t nsl = (int64_t)p.g.W * p.g.Q * p.g.Q;
+    const size_t elems = (size_t)nsl * p.g.P * p.g.gh * p.g.gw;
+    GH_CHECK(ws_reserve(ctx, ctx->ktab, elems * 16));
+    int blocks = (int)((elems + 255) / 256);
+    if (blocks > ctx->num_cu * 16) blocks = ctx->num_cu * 16;
+    hipLaunchKernelGGL(pad_kernels_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p.g, nsl, (const double2 *)gcf,
+                       (double2 *)ctx->ktab.ptr);
+    GH_CHECK_HIP(ctx, hipGetLastError());
+    *out = (const double *)ctx->ktab.ptr;
+    return GRIDHIP_OK;
+}
+
+}  // namespace gridhip
 
 extern "C" {
 
@@ -86,45 +182,31 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
     if (!gcf || (n > 0 && !vis)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
     if (W <= 0 || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel shape");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->opt.variant == 1) {
+    Prep p;
+    if (ctx->opt.variant == 1)
+        p.direct = true;
+    else
+        GH_CHECK(prepare(ctx, H, Wd, W, Q, gh, gw, n, &p));
+    if (p.direct) {
         mark(ctx, 0);
         mark(ctx, 1);
         GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
         mark(ctx, 2);
-            return GRIDHIP_OK;
+        return GRIDHIP_OK;
     }
-    Geom g;
-    int block;
-    size_t lds;
-    int rc = make_geom(ctx, H, Wd, W, Q, gh, gw, n, &g, &block, &lds);
-    if (rc == GRIDHIP_EUNSUPPORTED && ctx->opt.tile == 0) {
-        // support too large for an LDS tile: direct global-atomic scatter
-        mark(ctx, 0);
-        mark(ctx, 1);
-        GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
-        mark(ctx, 2);
-            return GRIDHIP_OK;
-    }
-    GH_CHECK(rc);
-    // tap-reusing variant: the work item's records are sorted by slice in LDS, which bounds the chunk
-    int nkeys = 0, maxchunk = 0;
-    size_t lds_sorted = 0;
-    // sort: 0 = auto (on when a work item holds enough visibilities for slices to repeat), 1 = on, 2 = off
-    const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)g.nbins >= 256);
-    const bool sorted = want_sort && sorted_plan(ctx, g, block, &nkeys, &maxchunk, &lds_sorted);
-    // a sorted work item may span several LDS batches; keep it big enough to flush each tile once
-    if (sorted) g.chunk = maxchunk;
     // scratch is sized before the timed region begins
-    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
+    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(p.g)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(p.nrec > 0 ? p.nrec : 1) * sizeof(VisRec)));
     mark(ctx, 0);
-    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin));
+    const double *tk = gcf;
+    GH_CHECK(tile_kernels(ctx, p, gcf, &tk));
+    GH_CHECK(launch_bin(ctx, p.g, p.nrec, u, v, uv_stride, wbin));
     mark(ctx, 1);
     if (n > 0) {
-        if (sorted)
-            GH_CHECK(launch_tile_grid_sorted(ctx, g, block, lds_sorted, nkeys, maxchunk, n, gcf, vis, grid, false));
+        if (p.sorted)
+            GH_CHECK(launch_tile_grid_sorted(ctx, p.g, p.block, p.lds_sorted, p.nkeys, p.batch, p.nrec, tk, vis, grid, false));
         else
-            GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, gcf, vis, grid));
+            GH_CHECK(launch_tile_grid(ctx, p.g, p.block, p.lds, p.nrec, tk, vis, grid));
     }
     mark(ctx, 2);
     return GRIDHIP_OK;
@@ -146,28 +228,24 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     if (!gcf || (n > 0 && !vis_out)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
     if (W <= 0 || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel shape");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    Geom g;
-    int block;
-    size_t lds;
-    GH_CHECK(make_geom(ctx, H, Wd, W, Q, gh, gw, n, &g, &block, &lds));
-    int nkeys = 0, batch = 0;
-    size_t lds_sorted = 0;
-    const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)g.nbins >= 256);
-    const bool sorted = want_sort && sorted_plan(ctx, g, block, &nkeys, &batch, &lds_sorted);
-    if (sorted) g.chunk = batch;
-    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
+    Prep p;
+    GH_CHECK(prepare(ctx, H, Wd, W, Q, gh, gw, n, &p));
+    if (p.direct) return fail(ctx, GRIDHIP_EUNSUPPORTED, "degrid2: support %lldx%lld too large for an LDS tile", (long long)gh, (long long)gw);
+    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(p.g)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(p.nrec > 0 ? p.nrec : 1) * sizeof(VisRec)));
     mark(ctx, 0);
     // visibilities with no tap inside the grid (or an out-of-range wbin) predict 0
     if (n > 0) GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)n * 16, ctx->stream));
-    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, wbin));
+    const double *tk = gcf;
+    GH_CHECK(tile_kernels(ctx, p, gcf, &tk));
+    GH_CHECK(launch_bin(ctx, p.g, p.nrec, u, v, uv_stride, wbin));
     mark(ctx, 1);
     if (n > 0) {
-        if (sorted)  // the sorted kernel's degrid mode reads `grid` and writes the vis array
-            GH_CHECK(launch_tile_grid_sorted(ctx, g, block, lds_sorted, nkeys, batch, n, gcf, vis_out,
+        if (p.sorted)  // the sorted kernel's degrid mode reads `grid` and writes the vis array
+            GH_CHECK(launch_tile_grid_sorted(ctx, p.g, p.block, p.lds_sorted, p.nkeys, p.batch, p.nrec, tk, vis_out,
                                              const_cast<double *>(grid), true));
         else
-            GH_CHECK(launch_tile_degrid(ctx, g, block, lds, n, gcf, grid, vis_out));
+            GH_CHECK(launch_tile_degrid(ctx, p.g, p.block, p.lds, p.nrec, tk, grid, vis_out));
     }
     mark(ctx, 2);
     return GRIDHIP_OK;

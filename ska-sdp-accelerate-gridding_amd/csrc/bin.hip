@@ -39,14 +39,32 @@ struct BinOut {
     int32_t lxy, kslice;
 };
 
-__device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, int64_t wb, int64_t k)
+// Element e of the pre-pass's stream is part (e % P) of visibility e / P (P = 1: the visibility itself).
+__device__ __forceinline__ void elem_of(const Geom &g, int64_t e, int64_t *k, int *part)
+{
+    if (g.P == 1) {
+        *k = e;
+        *part = 0;
+    } else {
+        const uint32_t kk = (uint32_t)e / (uint32_t)g.P;  // (e < 2^31)
+        *k = kk;
+        *part = (int)((uint32_t)e - kk * (uint32_t)g.P);
+    }
+}
+
+__device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, int64_t wb, int64_t k, int part)
 {
     BinOut o;
     int64_t x, y;
     int32_t xf, yf;
     frac_coord_dev(g.Wd, g.Q, pu, &x, &xf);
     frac_coord_dev(g.H, g.Q, pv, &y, &yf);
-    const int64_t x0 = x - g.gw / 2, y0 = y - g.gh / 2;
+    int64_t x0 = x - g.fgw / 2, y0 = y - g.fgh / 2;
+    if (g.P > 1) {  // this part's corner of the footprint
+        const int qy = part / g.px, qx = part - qy * g.px;
+        x0 += qx * g.gw;
+        y0 += qy * g.gh;
+    }
     // NaN coordinates compare false everywhere below and are dropped by the first test
     if (!(pu == pu) || !(pv == pv) || x0 <= -(int64_t)g.gw || x0 >= g.Wd || y0 <= -(int64_t)g.gh ||
         y0 >= g.H) {
@@ -56,7 +74,7 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
         return o;
     }
     if (wb < 0 || wb >= g.W) {
-        o.bin = -2;
+        o.bin = part == 0 ? -2 : -1;  // (counted once per visibility)
         o.lxy = 0;
         o.kslice = 0;
         return o;
@@ -67,7 +85,7 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
     const int32_t grp = ((int32_t)wb * g.ngroups) / g.W;  // 32-bit: W * ngroups < 2^31
     o.bin = grp * g.ntiles + ty * g.ntx + tx;
     o.lxy = (ly << 16) | lx;
-    o.kslice = g.per_vis ? (int32_t)k : ((int32_t)wb * g.Q + yf) * g.Q + xf;
+    o.kslice = g.per_vis ? (int32_t)k : (((int32_t)wb * g.Q + yf) * g.Q + xf) * g.P + part;
     return o;
 }
 
@@ -152,7 +170,7 @@ __device__ __forceinline__ void block_range(int64_t n, int64_t *lo, int64_t *hi)
     if (*lo > n) *lo = n;
 }
 
-template <bool LDS_HIST>
+template <bool LDS_HIST, int UN = 1>
 __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, const double *__restrict__ u,
                                                          const double *__restrict__ v, int64_t stride,
                                                          const int64_t *__restrict__ wbin,
@@ -175,21 +193,49 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
     int dropped = 0;
     const bool from_pre = pre && pf.bin_bits < 0;
     const PreFmt rf = {from_pre ? -pf.bin_bits : pf.bin_bits};
-    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        BinOut b;
-        if (from_pre)
-            b = pre_unpack(rf, pre[k]);
-        else {
-            b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
-            if (pre) pre[k] = pre_pack(rf, b);
+    // four visibilities per thread and trip: their 12 loads are in flight together (one work-group per CU has
+    // nothing else to cover the memory latency with)
+    for (int64_t k0 = lo + threadIdx.x; k0 < hi; k0 += (int64_t)UN * blockDim.x) {
+        BinOut b[UN];
+        if (from_pre) {
+            unsigned long long p[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                const int64_t k = k0 + (int64_t)q * blockDim.x;
+                p[q] = k < hi ? pre[k] : ~0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < UN; ++q) b[q] = pre_unpack(rf, p[q]);
+        } else {
+            double pu[UN], pv[UN];
+            int64_t wb[UN], kk[UN];
+            int part[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                const int64_t e = min(k0 + (int64_t)q * blockDim.x, hi - 1);  // (loads unconditional, indices clamped)
+                elem_of(g, e, &kk[q], &part[q]);
+                pu[q] = u[kk[q] * stride];
+                pv[q] = v[kk[q] * stride];
+                wb[q] = wbin ? wbin[kk[q]] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                const int64_t e = k0 + (int64_t)q * blockDim.x;
+                b[q] = vis_bin(g, pu[q], pv[q], wb[q], kk[q], part[q]);
+                if (e >= hi) b[q].bin = -1;
+                else if (pre) pre[e] = pre_pack(rf, b[q]);
+            }
         }
-        if (b.bin >= 0) {
-            if (LDS_HIST) {
-                if (b.bin >= bin_lo && b.bin < bin_hi) atomicAdd(&hist[b.bin - bin_lo], 1);
-            } else
-                atomicAdd(&bin_count[b.bin], 1);
-        } else if (b.bin == -2)
-            ++dropped;
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            if (b[q].bin >= 0) {
+                if (LDS_HIST) {
+                    if (b[q].bin >= bin_lo && b[q].bin < bin_hi) atomicAdd(&hist[b[q].bin - bin_lo], 1);
+                } else
+                    atomicAdd(&bin_count[b[q].bin], 1);
+            } else if (b[q].bin == -2)
+                ++dropped;
+        }
     }
     if (dropped && bin_lo == 0) atomicAdd(&scalars[0], dropped);
     if (LDS_HIST) {
@@ -324,8 +370,11 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
         __syncthreads();
     }
     int bad = 0;
-    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
+    for (int64_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        int64_t k;
+        int part;
+        elem_of(g, e, &k, &part);
+        BinOut b = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k, part);
         if (b.bin < 0) continue;
         if (LDS_HIST && (b.bin < bin_lo || b.bin >= bin_hi)) continue;
         int slot;
@@ -404,6 +453,16 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
     int64_t lo, hi;
     block_range(n, &lo, &hi);
     int bad = 0;
+    // The next chunk's pre-records travel while this chunk goes through its LDS phases (histogram, scan, sort):
+    // with one work-group per CU nothing else would keep the memory system busy meanwhile.
+    unsigned long long nxt[PER];
+    if (FROM_PRE) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t k = lo + q * NT + tid;
+            nxt[q] = k < hi ? pre[k] : ~0ull;
+        }
+    }
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         for (int i = tid; i < ncoarse; i += NT) hist[i] = 0;
         __syncthreads();
@@ -413,13 +472,17 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
         for (int q = 0; q < PER; ++q) {
             const int64_t k = c0 + q * NT + tid;
             b[q].bin = -1;
-            if (k < hi) {
-                if (FROM_PRE)
-                    b[q] = pre_unpack(pf, pre[k]);
-                else
-                    b[q] = vis_bin(g, u[k * stride], v[k * stride], wbin ? wbin[k] : 0, k);
-                if (b[q].bin >= g.nbins) b[q].bin = -1;  // (cannot happen)
+            if (FROM_PRE) {
+                b[q] = pre_unpack(pf, nxt[q]);
+                const int64_t kn = k + CHUNK;
+                nxt[q] = kn < hi ? pre[kn] : ~0ull;
+            } else if (k < hi) {
+                int64_t kv;
+                int part;
+                elem_of(g, k, &kv, &part);
+                b[q] = vis_bin(g, u[kv * stride], v[kv * stride], wbin ? wbin[kv] : 0, kv, part);
             }
+            if (b[q].bin >= g.nbins) b[q].bin = -1;  // (cannot happen)
         }
 #pragma unroll
         for (int q = 0; q < PER; ++q)
@@ -434,7 +497,10 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
         for (int q = 0; q < PER; ++q) {
             if (b[q].bin < 0) continue;
             TmpRec<T12> r;
-            r.set(b[q].lxy, b[q].kslice, (int32_t)(c0 + q * NT + tid), b[q].bin);
+            int64_t kv;
+            int part;
+            elem_of(g, c0 + q * NT + tid, &kv, &part);
+            r.set(b[q].lxy, b[q].kslice, (int32_t)kv, b[q].bin);
             sorted[hist[b[q].bin >> shift] + rank[q]] = r;
         }
         __syncthreads();
@@ -478,6 +544,12 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
     per = (per + CHUNK - 1) / CHUNK * CHUNK;
     const int64_t lo = min((int64_t)blockIdx.x * per, ntot), hi = min(lo + per, ntot);
     int bad = 0;
+    // (the next chunk's records travel while this chunk goes through its LDS phases, as in level 1)
+    TmpRec<T12> nxt[PER];
+    if (lo < hi) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(lo + q * NT + tid, hi - 1)];  // (unconditional: indices clamped)
+    }
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         const int64_t c1 = min(c0 + CHUNK, hi);
         int b_first = tmp[c0].bin(), b_last = tmp[c1 - 1].bin();
@@ -499,6 +571,8 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
                 }
                 out[slot] = r.final_rec();
             }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
             continue;
         }
         for (int i = tid; i < span; i += NT) hist[i] = 0;
@@ -510,7 +584,7 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
             const int64_t i = c0 + q * NT + tid;
             key[q] = -1;
             if (i < c1) {
-                r[q] = tmp[i];
+                r[q] = nxt[q];
                 key[q] = r[q].bin() - k0;
                 if ((uint32_t)key[q] >= (uint32_t)span || k0 + key[q] >= g.nbins) {  // tmp not ordered (cannot happen)
                     key[q] = -1;
@@ -518,6 +592,8 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
 #pragma unroll
         for (int q = 0; q < PER; ++q) rank[q] = key[q] >= 0 ? atomicAdd(&hist[key[q]], 1) : 0;
         __syncthreads();
@@ -544,17 +620,18 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
     if (bad) atomicAdd(&scalars[2], bad);
 }
 
-template <bool FROM_PRE, bool T12>
+// NT threads take chunks of CHUNK records: <1024, 8192> is one work-group per CU (LDS), <512, 4096> two, so that one
+// drains its stores and waits for its reservations while the other sorts.
+template <bool FROM_PRE, bool T12, int NT, int CHUNK>
 static int launch_two_level(gridhip_ctx *ctx, const Geom &g, const Tables &t, int64_t n, const double *u, const double *v,
                             int64_t uv_stride, const int64_t *wbin, int shift, int ncoarse, int cblocks,
                             const unsigned long long *pre, PreFmt pf, int32_t cap)
 {
-    constexpr int CHUNK = 8192;
     const size_t coarse_lds = (size_t)CHUNK * sizeof(TmpRec<T12>) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
     const size_t fine_lds = (size_t)CHUNK * sizeof(TmpRec<T12>) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
-    auto coarse = coarse_scatter_kernel<1024, CHUNK, FROM_PRE, T12>;
-    auto fine = fine_scatter_kernel<1024, CHUNK, T12>;
-    const uint32_t bit = 2u << ((FROM_PRE ? 1 : 0) + (T12 ? 2 : 0));
+    auto coarse = coarse_scatter_kernel<NT, CHUNK, FROM_PRE, T12>;
+    auto fine = fine_scatter_kernel<NT, CHUNK, T12>;
+    const uint32_t bit = 2u << ((FROM_PRE ? 1 : 0) + (T12 ? 2 : 0) + (NT == 512 ? 4 : 0));
     if (!(ctx->attr_mask & bit)) {
         GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
         GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
@@ -562,9 +639,9 @@ static int launch_two_level(gridhip_ctx *ctx, const Geom &g, const Tables &t, in
     }
     int32_t *ccur = (int32_t *)ctx->blockhist.ptr;
     TmpRec<T12> *tmp = (TmpRec<T12> *)ctx->recs_tmp.ptr;
-    hipLaunchKernelGGL(coarse, dim3(cblocks), dim3(1024), coarse_lds, ctx->stream, g, n, u, v, uv_stride, wbin, t.bin_start,
+    hipLaunchKernelGGL(coarse, dim3(cblocks), dim3(NT), coarse_lds, ctx->stream, g, n, u, v, uv_stride, wbin, t.bin_start,
                        ccur, shift, ncoarse, tmp, pre, pf, cap, t.scalars);
-    hipLaunchKernelGGL(fine, dim3(cblocks), dim3(1024), fine_lds, ctx->stream, g, t.bin_start, t.cursor, shift,
+    hipLaunchKernelGGL(fine, dim3(cblocks), dim3(NT), fine_lds, ctx->stream, g, t.bin_start, t.cursor, shift,
                        (const TmpRec<T12> *)tmp, (VisRec *)ctx->recs.ptr, cap, t.scalars);
     return GRIDHIP_OK;
 }
@@ -603,7 +680,9 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     if (need < 1) need = 1;
     if (blocks > need) blocks = (int)need;
     if (lds_hist && !(ctx->attr_mask & 1u)) {
-        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true>,
+        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true, 1>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true, 4>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
         GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_scatter_kernel<true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
@@ -611,7 +690,14 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     }
 
     // two-level scatter for large streams (only the counting sweep needs the histogram windows)
-    int shift = 6;
+    // bins per coarse bin = 2^shift.  Level 1 writes runs of chunk / ncoarse records, level 2 of chunk / 2^shift:
+    // balanced (both ~ sqrt) keeps every run above 256 B
+    int shift = (int)ctx->opt.coarse_shift;
+    if (shift <= 0) {
+        shift = 6;
+        while (shift < 9 && (1 << (2 * shift)) < g.nbins) ++shift;
+    }
+    if (shift > 10) shift = 10;  // (level 2 sorts at most 1024 bins per coarse bin in LDS)
     while (((g.nbins + (1 << shift) - 1) >> shift) > 1024) ++shift;
     const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
     const bool two_level = lds_hist && (p == 2 || p == 4 || p == 5 || (p == 0 && n >= ((int64_t)1 << 22)));
@@ -620,12 +706,15 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * (t12 ? 12 : 16)));
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));  // coarse cursors
         GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->blockhist.ptr, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
-        int cblocks = ctx->num_cu;  // (8192-record chunks: one work-group per CU)
-        int64_t cneed = (n + 4 * 8192 - 1) / (4 * 8192);
+        // chunk size: 8192 records, one work-group per CU (option scatter_chunk = 4096: two per CU; measured no faster)
+        const bool small_chunk = ctx->opt.scatter_chunk == 4096;
+        const int chunk = small_chunk ? 4096 : 8192;
+        int cblocks = ctx->num_cu * (small_chunk ? 2 : 1);
+        int64_t cneed = (n + 4 * chunk - 1) / (4 * chunk);
         if (cblocks > cneed) cblocks = (int)(cneed < 1 ? 1 : cneed);
         // pre-records: when bin | lx | ly | kslice fit one 64-bit word
         const int bb = bits_for(g.nbins);
-        const int64_t nslices = g.per_vis ? (n > 0 ? n : 1) : (int64_t)g.W * g.Q * g.Q;
+        const int64_t nslices = g.nslices;
         const bool use_pre = p != 4 && g.T <= 128 && bb + 14 + bits_for(nslices) <= 63;
         unsigned long long *pre = nullptr;
         if (use_pre) {
@@ -634,21 +723,32 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         }
         for (int wdw = 0; wdw < windows; ++wdw) {
             const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
-            hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
-                               uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
-                               PreFmt{wdw == 0 ? bb : -bb}, pre);
+            if (ctx->opt.count_unroll == 4)
+                hipLaunchKernelGGL((bin_count_kernel<true, 4>), dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
+                                   uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
+                                   PreFmt{wdw == 0 ? bb : -bb}, pre);
+            else
+                hipLaunchKernelGGL((bin_count_kernel<true, 1>), dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
+                                   uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
+                                   PreFmt{wdw == 0 ? bb : -bb}, pre);
         }
         hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                            t.work_start, t.cursor);
         const PreFmt pf{bb};
+#define GH_TWO(P_, T_)                                                                                                  \
+    (small_chunk ? launch_two_level<P_, T_, 512, 4096>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, \
+                                                        pf, cap)                                                          \
+                 : launch_two_level<P_, T_, 1024, 8192>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks,   \
+                                                         pre, pf, cap))
         if (use_pre && t12)
-            GH_CHECK((launch_two_level<true, true>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
+            GH_CHECK(GH_TWO(true, true));
         else if (use_pre)
-            GH_CHECK((launch_two_level<true, false>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
+            GH_CHECK(GH_TWO(true, false));
         else if (t12)
-            GH_CHECK((launch_two_level<false, true>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
+            GH_CHECK(GH_TWO(false, true));
         else
-            GH_CHECK((launch_two_level<false, false>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks, pre, pf, cap)));
+            GH_CHECK(GH_TWO(false, false));
+#undef GH_TWO
         GH_CHECK_HIP(ctx, hipGetLastError());
         return GRIDHIP_OK;
     }

@@ -39,10 +39,16 @@ struct Geom {
     int32_t per_vis;      // 1: the kernel table holds one [gh][gw] slice per visibility (aw gridders)
     int32_t nvis;         // visibilities of the call: a record's `orig` is below it
     int32_t nslices;      // [gh][gw] slices in the kernel table: a record's `kslice` is below it
+    // Sub-footprints.  A kernel the tap-reusing tile kernel has no instantiation for (supports above 16, non-square
+    // ones) is cut into py x px square parts of side gh = gw = sub <= 16 (zero-padded: pad_kernels): every
+    // visibility becomes P = py * px records, each with its own footprint origin, tile and slice
+    // (kslice * P + part), and the kernels see nothing but more visibilities of a small square support.
+    // fgh x fgw is the kernel the caller passed (the footprint origin is x - fgw / 2, y - fgh / 2).
+    int32_t fgh, fgw, px, py, P;
 };
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0;
 };
 
 struct Workspace {
@@ -66,6 +72,7 @@ struct gridhip_ctx {
     gridhip::Workspace recs_raw;   // 8-byte pre-records the counting sweep leaves for the scatter (bin.hip)
     gridhip::Workspace recs_tmp;   // coarse-binned records between the two scatter levels of the pre-pass (bin.hip)
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
+    gridhip::Workspace ktab;       // kernel table cut into zero-padded square parts (sub-footprints, api.hip)
     int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=aw drops, [2]=errors, [4..19] work queues,
                                    // [20..27] clock stamps of the last sorted tile kernel, [32..] profile
     int num_cu = 256;
@@ -153,6 +160,19 @@ int launch_direct_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
                        int64_t W, int64_t Q, int64_t gh, int64_t gw, const double *gcf,
                        const double *u, const double *v, int64_t uv_stride,
                        const int64_t *wbin, const double *vis);
+// Everything a gridding call decides before it enqueues: geometry, which tile kernel, scratch sizes.
+struct Prep {
+    Geom g;
+    int block = 0;
+    size_t lds = 0, lds_sorted = 0;
+    int nkeys = 0, batch = 0;
+    bool sorted = false;  // the tap-reusing tile kernel (tile_sorted.hip)
+    bool direct = false;  // no LDS tile possible: direct global-atomic scatter
+    int64_t nrec = 0;     // records the pre-pass produces at most: n * g.P
+};
+int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh, int64_t gw, int64_t n, Prep *p);
+// the kernel table the tile kernels read: gcf itself, or (sub-footprints) its zero-padded parts in ctx->ktab
+int tile_kernels(gridhip_ctx *ctx, const Prep &p, const double *gcf, const double **out);
 int launch_simple_grid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n,
                        const double *u, const double *v, int64_t uv_stride, const double *vis);
 

@@ -89,6 +89,9 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->gw = (int32_t)gw;
     g->nvis = (int32_t)(n > 0 ? n : 1);
     g->nslices = (int32_t)(W * Q * Q);
+    g->fgh = (int32_t)gh;
+    g->fgw = (int32_t)gw;
+    g->px = g->py = g->P = 1;
 
     const size_t lds_cap = (size_t)ctx->max_lds - 1024;
     int T = (int)ctx->opt.tile;
@@ -236,7 +239,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     fft_release(ctx);
-    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp, &ctx->recs_raw};
+    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp, &ctx->recs_raw, &ctx->ktab};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -287,6 +290,9 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "prepass")) return &ctx->opt.prepass;
     if (!strcmp(key, "fault_inject")) return &ctx->opt.fault_inject;
     if (!strcmp(key, "aw_cache")) return &ctx->opt.aw_cache;
+    if (!strcmp(key, "coarse_shift")) return &ctx->opt.coarse_shift;
+    if (!strcmp(key, "scatter_chunk")) return &ctx->opt.scatter_chunk;
+    if (!strcmp(key, "count_unroll")) return &ctx->opt.count_unroll;
     return nullptr;
 }
 

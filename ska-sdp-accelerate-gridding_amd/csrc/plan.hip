@@ -11,12 +11,8 @@
 
 struct gridhip_plan {
     gridhip_ctx *ctx = nullptr;
-    gridhip::Geom g;
+    gridhip::Prep p;
     gridhip::Workspace recs, tables;
-    int block = 0;
-    size_t lds = 0, lds_sorted = 0;
-    int nkeys = 0, batch = 0;
-    bool sorted = false;
     int64_t n = 0;
 };
 
@@ -56,19 +52,17 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
     if (!p) return GRIDHIP_ENOMEM;
     p->ctx = ctx;
     p->n = n;
-    int rc = make_geom(ctx, H, Wd, W, Q, gh, gw, n, &p->g, &p->block, &p->lds);
+    int rc = prepare(ctx, H, Wd, W, Q, gh, gw, n, &p->p);
+    if (rc == GRIDHIP_OK && p->p.direct) rc = fail(ctx, GRIDHIP_EUNSUPPORTED, "plan: support too large for an LDS tile");
     if (rc != GRIDHIP_OK) {
         delete p;
         return rc;
     }
-    const bool want_sort = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)p->g.nbins >= 256);
-    p->sorted = want_sort && sorted_plan(ctx, p->g, p->block, &p->nkeys, &p->batch, &p->lds_sorted);
-    if (p->sorted) p->g.chunk = p->batch;
     {
         Lend lend(p);
-        rc = ws_reserve(ctx, ctx->tables, tables_bytes(p->g));
-        if (rc == GRIDHIP_OK) rc = ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec));
-        if (rc == GRIDHIP_OK) rc = launch_bin(ctx, p->g, n, u, v, uv_stride, wbin);
+        rc = ws_reserve(ctx, ctx->tables, tables_bytes(p->p.g));
+        if (rc == GRIDHIP_OK) rc = ws_reserve(ctx, ctx->recs, (size_t)(p->p.nrec > 0 ? p->p.nrec : 1) * sizeof(VisRec));
+        if (rc == GRIDHIP_OK) rc = launch_bin(ctx, p->p.g, p->p.nrec, u, v, uv_stride, wbin);
     }
     if (rc != GRIDHIP_OK) {
         gridhip_plan_destroy(p);
@@ -98,11 +92,13 @@ int gridhip_plan_grid_dev(gridhip_plan *p, const double *gcf, const double *vis,
     if (!gcf || !grid || (p->n > 0 && !vis)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     if (p->n == 0) return GRIDHIP_OK;
+    const double *tk = gcf;
+    GH_CHECK(tile_kernels(ctx, p->p, gcf, &tk));
     Lend lend(p);
-    if (p->sorted)
-        return launch_tile_grid_sorted(ctx, p->g, p->block, p->lds_sorted, p->nkeys, p->batch, p->n, gcf, vis, grid,
-                                       false);
-    return launch_tile_grid(ctx, p->g, p->block, p->lds, p->n, gcf, vis, grid);
+    const Prep &q = p->p;
+    if (q.sorted)
+        return launch_tile_grid_sorted(ctx, q.g, q.block, q.lds_sorted, q.nkeys, q.batch, q.nrec, tk, vis, grid, false);
+    return launch_tile_grid(ctx, q.g, q.block, q.lds, q.nrec, tk, vis, grid);
 }
 
 // vis_out[k] = gather(kernels x G) for every baseline of the plan (degrid2 semantics)
@@ -114,11 +110,14 @@ int gridhip_plan_degrid_dev(gridhip_plan *p, const double *gcf, const double *gr
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     if (p->n == 0) return GRIDHIP_OK;
     GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)p->n * 16, ctx->stream));
+    const double *tk = gcf;
+    GH_CHECK(tile_kernels(ctx, p->p, gcf, &tk));
     Lend lend(p);
-    if (p->sorted)
-        return launch_tile_grid_sorted(ctx, p->g, p->block, p->lds_sorted, p->nkeys, p->batch, p->n, gcf, vis_out,
+    const Prep &q = p->p;
+    if (q.sorted)
+        return launch_tile_grid_sorted(ctx, q.g, q.block, q.lds_sorted, q.nkeys, q.batch, q.nrec, tk, vis_out,
                                        const_cast<double *>(grid), true);
-    return launch_tile_degrid(ctx, p->g, p->block, p->lds, p->n, gcf, grid, vis_out);
+    return launch_tile_degrid(ctx, q.g, q.block, q.lds, q.nrec, tk, grid, vis_out);
 }
 
 }  // extern "C"

@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
         }
         GH_STAMP(0)  // work fetch
         const int first_plane = (grp * g.W + g.ngroups - 1) / g.ngroups;  // smallest wb with wb*ng/W == grp
-        const int first_slice = first_plane * g.Q * g.Q;
+        const int first_slice = first_plane * g.Q * g.Q * g.P;
         double2 *svals = svals_wg + (size_t)slot * batch;
         uint2 *smo = smo_wg + (size_t)slot * batch;
         const int b_lo = w.v_lo;
@@ -417,7 +417,13 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                         const int row = lane >> 4;
                         if ((lane & 15) == 15 && i + row < len) {
                             const int32_t o = row == 0 ? oo[0] : row == 1 ? oo[1] : row == 2 ? oo[2] : oo[3];
-                            vis[o] = make_double2(rr, ri);
+                            if (g.P == 1)
+                                vis[o] = make_double2(rr, ri);
+                            else {  // sub-footprints: a visibility's parts are summed (vis_out was cleared)
+                                double *dst = reinterpret_cast<double *>(vis + o);
+                                unsafeAtomicAdd(dst, rr);
+                                unsafeAtomicAdd(dst + 1, ri);
+                            }
                         }
                     }
                 }
@@ -491,7 +497,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
         const SortedItem d = desc[cur];
         if (!d.valid) break;  // uniform across the work-group
         const int first_plane = (d.grp * g.W + g.ngroups - 1) / g.ngroups;
-        const int first_slice = first_plane * g.Q * g.Q;
+        const int first_slice = first_plane * g.Q * g.Q * g.P;
         const int tx = d.tile % g.ntx, ty = d.tile / g.ntx;
         const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
         if (DEGRID) {
@@ -560,7 +566,7 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     if (g.gh != g.gw || g.gh < 5 || g.gh > 16) return false;
     if (g.per_vis || g.T > 128) return false;
     const int planes = (g.W + g.ngroups - 1) / g.ngroups + 1;  // groups differ by at most one plane
-    const int64_t keys = (int64_t)planes * g.Q * g.Q;
+    const int64_t keys = (int64_t)planes * g.Q * g.Q * g.P;
     if (keys >= 65536) return false;
     const size_t plane = (size_t)g.lrows * g.ldw * 8;
     if (plane > (size_t)SORTED_IM_OFF) return false;

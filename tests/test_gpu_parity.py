@@ -288,6 +288,52 @@ def test_degrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
     assert rel(got, ref) < TOL
 
 
+@pytest.mark.parametrize("N,M,W,Q,gh,gw,n,opts", [
+    (320, 320, 8, 4, 17, 17, 60000, {}),                # 2 x 2 parts of 9
+    (320, 320, 8, 2, 21, 21, 60000, {}),                # 2 x 2 parts of 11
+    (384, 384, 4, 2, 31, 31, 40000, {}),                # 2 x 2 parts of 16: the support of the reference's scripts
+    (384, 320, 4, 2, 31, 31, 40000, {"tile": 32, "wgroups": 2}),
+    (256, 256, 8, 4, 9, 5, 60000, {}),                  # one 9 x 9 part, zero-padded
+    (256, 192, 4, 2, 5, 20, 50000, {}),                 # 1 x 2 parts of 10
+    (256, 256, 2, 2, 40, 33, 20000, {}),                # 3 x 3 parts of 14
+    (200, 200, 4, 4, 3, 3, 50000, {}),                  # below the smallest instantiation: padded to 5 x 5
+    (128, 128, 1, 1, 1, 1, 30000, {}),
+])
+@pytest.mark.parametrize("dist", ["uniform", "core"])
+def test_subfootprints_large_and_nonsquare_supports(ctx, oracle, N, M, W, Q, gh, gw, n, opts, dist):
+    """Supports above 16 and non-square kernels through the tap-reusing kernel: the kernel is cut into zero-padded
+    square parts and every visibility becomes one record per part (own footprint origin, tile and slice).
+    Grid, degrid (a visibility's parts are summed), a plan, and coordinates spilling over the grid edges."""
+    import torch
+    gcf, u, v, wb, vis = case(N + gh * 3 + gw, N, M, W, Q, gh, gw, n, spread=0.58, dist=dist)
+    ref = oracle.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
+    rng = np.random.default_rng(9)
+    G = rng.normal(size=(N, M)) + 1j * rng.normal(size=(N, M))
+    dref = oracle.degrid2(gcf, G, u, v, wb)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    try:
+        ctx.set_option("sort", 1)
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        got = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
+        e1 = ctx.get_option("errors")
+        d = ctx.degrid2(gcf, G, (u, v, None), wb)
+        e2 = ctx.get_option("errors")
+        plan = ctx.plan((N, M), gcf.shape, (t(u), t(v), None), t(wb))
+        pg = plan.grid(t(gcf), torch.zeros((N, M), dtype=torch.complex128, device=dev), t(vis)).cpu().numpy()
+        pd = plan.degrid(t(gcf), t(G)).cpu().numpy()
+        plan.close()
+        ctx.set_option("prepass", 2)   # the two-level scatter with pre-records, one record per part
+        got2 = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
+    finally:
+        for k in ("sort", "tile", "block", "wgroups", "prepass"):
+            ctx.set_option(k, 0)
+    assert e1 == 0 and e2 == 0
+    assert rel(got, ref) < TOL and rel(got2, ref) < TOL and rel(pg, ref) < TOL
+    assert rel(d, dref) < TOL and rel(pd, dref) < TOL
+
+
 @pytest.mark.parametrize("N,W,Q,S,n,opts", [(512, 32, 8, 15, 150000, {}), (300, 16, 4, 7, 80000, {}),
                                              (256, 8, 4, 9, 60000, {}), (256, 8, 2, 13, 60000, {}),
                                              (512, 32, 8, 15, 150000, {"tile": 64, "wgroups": 8}),
