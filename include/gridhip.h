@@ -74,7 +74,7 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *   "tile"      grid-tile side T in cells (power of two, 8..128; 0 = auto)
  *   "block"     threads per work-group of the tile kernels (multiple of 64, <=1024; 0 = auto)
  *   "chunk"     max visibilities per work item (0 = auto; the sorted kernel takes at most 16384)
- *   "wgroups"   number of w-plane groups work items are split into for XCD/L2 locality (1..8; 0 = auto)
+ *   "wgroups"   number of w-plane groups work items are split into for XCD/L2 locality (1..16; 0 = auto)
  *   "variant"   0 = LDS-tile accumulate (default), 1 = direct global-atomic scatter (baseline)
  *   "sort"      order each work item's records by kernel slice so that runs of visibilities
  *               reuse their taps from registers: 0 = auto, 1 = on (when the shape allows), 2 = off
@@ -87,10 +87,11 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               the visibilities that share it reuse it; 0 = one kernel per visibility (as the reference evaluates)
  *   "fault_inject"  TEST HOOK: hides the last k slots of the record array from the pre-pass's scatter so that its
  *               bounds checks have something to reject (counted in "errors"; results are then incomplete)
- *   "dbg"       ablation / profiling switch for tuning runs (0 = off; results are wrong with most values)
+ *   ("dbg", the ablation / profiling switch of tuning runs, exists only in the tuning build of the library,
+ *   `make -C csrc tuning` -> lib/libgridhip_tuning.so; the shipped library rejects the key)
  * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel
  * launch (expected 0); "clock_khz" = shader clock held during the last tap-reusing tile kernel (in-kernel
- * s_memtime / s_memrealtime stamps); "prof0".."prof31" = cycle counters of a dbg=16 launch (tools/phase_profile.py).
+ * s_memtime / s_memrealtime stamps); "prof0".."prof31" = cycle counters of a dbg=16 launch of the tuning build (tools/phase_profile.py).
  */
 int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value);
 int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value);

@@ -128,13 +128,14 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     int ng = (int)ctx->opt.wgroups;
     if (ng == 0) {
         ng = (W >= 8 && n / ((int64_t)g->ntiles * 8) >= 256) ? 8 : 1;
-        // very large grids: 8 groups would need more than two LDS-histogram windows in the pre-pass
-        // (each window re-reads the stream); 4 groups measured faster there (8192^2: 31.4 vs 33.2 ms)
+        // very large grids: the pre-pass counts the bins in LDS-histogram windows; each window after the first
+        // re-reads the 8-byte pre-records (0.2 ms per 10^8).  Up to four windows 8 groups still win
+        // (8192^2, 1.25 x 10^8 visibilities: 21.2 ms against 21.9 with 4 groups, 25.5 with 16)
         const int64_t cap = ((int64_t)ctx->max_lds - 8192) / 4;
-        if (ng == 8 && (int64_t)g->ntiles * 8 > 2 * cap) ng = 4;
+        if (ng == 8 && (int64_t)g->ntiles * 8 > 4 * cap) ng = 4;
     }
     if (ng > W) ng = (int)W;
-    if (ng < 1 || ng > 8) return fail(ctx, GRIDHIP_EINVAL, "wgroups must be in 1..8");
+    if (ng < 1 || ng > 16) return fail(ctx, GRIDHIP_EINVAL, "wgroups must be in 1..16");
     g->ngroups = ng;
     g->nbins = ng * g->ntiles;
 
@@ -286,7 +287,9 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "wgroups")) return &ctx->opt.wgroups;
     if (!strcmp(key, "variant")) return &ctx->opt.variant;
     if (!strcmp(key, "sort")) return &ctx->opt.sort;
-    if (!strcmp(key, "dbg")) return &ctx->opt.dbg;
+#ifdef GRIDHIP_TUNING
+    if (!strcmp(key, "dbg")) return &ctx->opt.dbg;  // ablation / profiling switch: tuning builds only (make tuning)
+#endif
     if (!strcmp(key, "prepass")) return &ctx->opt.prepass;
     if (!strcmp(key, "fault_inject")) return &ctx->opt.fault_inject;
     if (!strcmp(key, "aw_cache")) return &ctx->opt.aw_cache;

@@ -281,13 +281,16 @@ int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_byte
     } while (0)
 #define GH_CASE(S_) \
     case S_: GH_LAUNCH(S_, 0); break;
+#ifdef GRIDHIP_TUNING
     if (g.gh == 15 && g.gw == 15 && g.dbg == 1)
         GH_LAUNCH(15, 1);
     else if (g.gh == 15 && g.gw == 15 && g.dbg == 2)
         GH_LAUNCH(15, 2);
     else if (g.gh == 15 && g.gw == 15 && g.dbg == 3)
         GH_LAUNCH(15, 3);
-    else if (g.gh == g.gw)
+    else
+#endif
+    if (g.gh == g.gw)
         switch (g.gh) {
             GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)
             GH_CASE(14) GH_CASE(15) GH_CASE(16)

@@ -601,7 +601,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     GH_CHECK(ws_reserve(ctx, ctx->sorted, (size_t)nblk * 2 * batch * 24));
     double2 *svals = (double2 *)ctx->sorted.ptr;
     uint2 *smo = (uint2 *)(svals + (size_t)nblk * 2 * batch);
-    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 4, 0, 8 * sizeof(int32_t), ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 4, 0, 16 * sizeof(int32_t), ctx->stream));  // the w-groups' queues
     if (g.dbg & 16) GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 32, 0, 64 * sizeof(int32_t), ctx->stream));
 #define GH_LAUNCH(S_, D_)                                                                                        \
     do {                                                                                                         \
@@ -626,7 +626,9 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
         GH_CHECK_HIP(ctx, hipGetLastError());                                                                    \
         return GRIDHIP_OK;                                                                                       \
     }
+#ifdef GRIDHIP_TUNING  // ablation / phase-profile instantiations: tuning builds only (make tuning)
     GH_ABL(1) GH_ABL(2) GH_ABL(3) GH_ABL(4) GH_ABL(5) GH_ABL(7) GH_ABL(8) GH_ABL(15) GH_ABL(16)
+#endif
 #undef GH_ABL
     switch (g.gh) {
         GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)

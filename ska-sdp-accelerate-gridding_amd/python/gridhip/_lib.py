@@ -8,7 +8,8 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(_PKG, "..", ".."))          # ska-sdp-accelerate-gridding_amd/
-LIB_PATH = os.path.join(ROOT, "lib", "libgridhip.so")
+# GRIDHIP_LIB: another build of the same ABI (tools/ use lib/libgridhip_tuning.so, which has the "dbg" option)
+LIB_PATH = os.environ.get("GRIDHIP_LIB") or os.path.join(ROOT, "lib", "libgridhip.so")
 
 i64 = C.c_int64
 vp = C.c_void_p

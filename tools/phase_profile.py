@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of the sorted tile kernel (option dbg=16: thread 0 of every work-group stamps
-clock64 at each barrier).  usage: python tools/phase_profile.py [--workload cfg3] [opt=val,...]"""
+clock64 at each barrier).  usage: python tools/phase_profile.py [--workload=cfg3] [opt=val,...]"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the "dbg" option and the stamping instantiation exist in the tuning build only (make -C csrc tuning)
+os.environ.setdefault("GRIDHIP_LIB", os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "lib", "libgridhip_tuning.so"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "python"))
 import torch
 import bench
 import gridhip
 
-sets = [a for a in sys.argv[1:] if "=" in a] or [""]
-n, N, W, Q, S = bench.WORKLOADS["cfg3"]
+sets = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")] or [""]
+wl = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--workload=")]
+n, N, W, Q, S = bench.WORKLOADS[wl[0] if wl else "cfg3"]
 dev = torch.device("cuda:0")
 ctx = gridhip.Context(0)
 gcf = bench.synth_kernels(W, Q, S, dev)
