@@ -194,7 +194,8 @@ int gridhip_w_cache_imaging(gridhip_ctx *ctx, int64_t wstep, int64_t qpx, int64_
 /* convgrid3 / convgrid4, :246-396 (both produce this grid): per visibility
  * awkern = conj(aw_kernel_fn2 yf xf wkerns[wbin] akerns[a1] akerns[a2]) (:761-775, convolve2d :795-811 with
  * its transposing pad), G[y0+i,x0+j] += vis*awkern[i,j].  wkerns [W][Q][Q][S][S], akerns [A][S][S];
- * the index triple (wbin, a1, a2) is passed as three arrays (Accelerate's struct-of-arrays). */
+ * the index triple (wbin, a1, a2) is passed as three arrays (Accelerate's struct-of-arrays).
+ * The kernel of every distinct (a1, a2, wbin, yf, xf) is built once per call (option "aw_cache"). */
 int gridhip_awgrid(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W,
                    int64_t Q, int64_t S, int64_t A, const double *wkerns, const double *akerns,
                    const double *u, const double *v, int64_t uv_stride, const int64_t *wbin,
@@ -203,6 +204,9 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
                        int64_t Q, int64_t S, int64_t A, const double *wkerns, const double *akerns,
                        const double *u, const double *v, int64_t uv_stride, const int64_t *wbin,
                        const int64_t *a1, const int64_t *a2, const double *vis);
+/* What the last gridhip_awgrid / gridhip_awgrid_dev call on this context did (synchronises): visibilities that
+ * received a kernel, and distinct (a1, a2, wbin, yf, xf) kernels built for them (equal with "aw_cache" = 0). */
+int gridhip_aw_last_stats(gridhip_ctx *ctx, int64_t *vis_keyed, int64_t *kernels_built);
 /* aw_imaging / aw_imagingOld, :452-506: wvals are the W plane w-values searched by findClosest. */
 int gridhip_aw_imaging(gridhip_ctx *ctx, double theta, int64_t lam, int64_t W, int64_t Q, int64_t S,
                        int64_t A, const double *wkerns, const double *wvals, const double *akerns,

@@ -19,21 +19,6 @@ int check_common(gridhip_ctx *ctx, int64_t H, int64_t Wd, const void *grid, int6
     return GRIDHIP_OK;
 }
 
-// i = 0: a timed call starts, 1: its pre-pass is enqueued, 2: its dominant kernel is enqueued (the call is then
-// readable with gridhip_timing)
-void mark(gridhip_ctx *ctx, int i)
-{
-    if (!ctx->timing) return;
-    if (i == 0) ctx->ev_open = true;
-    if (!ctx->ev_open) return;
-    (void)hipEventRecord(ctx->ev[(ctx->ev_calls % gridhip_ctx::EV_RING) * 3 + i], ctx->stream);
-    if (i == 2) {
-        ctx->ev_open = false;
-        ++ctx->ev_calls;
-    }
-}
-
-
 // bump allocator over the staging workspace
 struct Stage {
     char *base;
@@ -252,30 +237,6 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
 }
 
 }  // extern "C"
-
-namespace gridhip {
-// convgrid with one private kernel slice per visibility (the aw gridders, awgrid.hip)
-int grid_per_vis_kernels(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t Q, int64_t gh,
-                         int64_t gw, const double *kperv, const double *u, const double *v, int64_t uv_stride,
-                         const double *vis)
-{
-    Geom g;
-    int block;
-    size_t lds;
-    const int64_t keep = ctx->opt.wgroups;
-    ctx->opt.wgroups = 1;  // every slice is used once: nothing for an L2 to keep
-    int rc = make_geom(ctx, H, Wd, 1, Q, gh, gw, n, &g, &block, &lds);
-    ctx->opt.wgroups = keep;
-    GH_CHECK(rc);
-    g.per_vis = 1;
-    g.nslices = g.nvis;  // one private slice per visibility
-    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
-    GH_CHECK(launch_bin(ctx, g, n, u, v, uv_stride, nullptr));
-    if (n > 0) GH_CHECK(launch_tile_grid(ctx, g, block, lds, n, kperv, vis, grid));
-    return GRIDHIP_OK;
-}
-}  // namespace gridhip
 
 extern "C" {
 

@@ -4,14 +4,19 @@
 //
 // The reference evaluates convolve2d with six 32x32 FFTs per visibility inside a sequential
 // `awhile`.  Its pad_mid transposes the operands (padder reads `array ! index2 oldx oldy`, :875),
-// so convolve2d(a, b) = same_conv(a, b)^T exactly; here that is evaluated directly in LDS:
+// so convolve2d(a, b) = same_conv(a, b)^T exactly; here that is evaluated directly:
 //   1. the antenna-pair product convolve2d(a1, a2) is computed once per pair that occurs;
-//   2. one work-group per visibility convolves it with its w-kernel slice and conjugates;
-//   3. the per-visibility kernels feed the same LDS-tile gridder as convgrid2 (per_vis mode).
-// Work is done in batches so the per-visibility kernel buffer stays bounded.
-#include "common.h"
+//   2. visibilities are de-duplicated by KEY = (pair, wbin, yf, xf) with a device hash table (option
+//      "aw_cache"; real data repeats a key over the consecutive dumps of a baseline): the kernel of every
+//      distinct key is built once, on the fp64 vector ALU (aw_build_kernel);
+//   3. the table of distinct kernels feeds the tap-reusing tile gridder (tile_sorted.hip, AW mode): a record's
+//      slice is its key's index, runs of equal key reuse their taps from registers.
+// Work is done in batches so the kernel table stays bounded; nothing is read back inside a call.
+#include "tile_common.h"
 
 namespace gridhip {
+
+constexpr uint64_t AW_EMPTY = ~0ull;
 
 // out[x*S + y] = sum_{i,j} a[i][j] * b[y-i+c][x-j+c]   (c = S/2; a, b in LDS)   == same_conv(a,b)^T
 __device__ __forceinline__ void conv_same_T(const double2 *a, const double2 *b, int S, double2 *out, bool conj)
@@ -35,242 +40,264 @@ __device__ __forceinline__ void conv_same_T(const double2 *a, const double2 *b, 
     }
 }
 
-__global__ void aw_mark_pairs_kernel(int64_t n, int64_t A, const int64_t *__restrict__ a1,
-                                     const int64_t *__restrict__ a2, int32_t *__restrict__ flag)
+// ---- 1. antenna pairs that occur -> dense slots (first come first served; nothing depends on the order)
+//   slot[p*A+q]: -1 unseen; counters[0] = pairs so far; pairlist[slot] = p*A+q
+__global__ void aw_pairs_kernel(int64_t n, int64_t A, const int64_t *__restrict__ a1, const int64_t *__restrict__ a2,
+                                int32_t *__restrict__ slot, int32_t *__restrict__ pairlist, int32_t *__restrict__ counters,
+                                int32_t cap)
 {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = a1[k], q = a2[k];
-        if (p >= 0 && p < A && q >= 0 && q < A) flag[p * A + q] = 1;
+        if (p < 0 || p >= A || q < 0 || q >= A) continue;
+        int32_t *s = slot + p * A + q;
+        if (*s != -1) continue;                    // (claimed already; a stale -1 only costs the atomic below)
+        if (atomicCAS(s, -1, -2) != -1) continue;  // somebody else claims it
+        const int32_t id = atomicAdd(&counters[0], 1);
+        if (id < cap) pairlist[id] = (int32_t)(p * A + q);
+        __hip_atomic_store(s, id < cap ? id : -3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// exclusive scan of flags -> slot index of every used pair; single work-group
-__global__ void __launch_bounds__(1024) aw_scan_pairs_kernel(int64_t m, const int32_t *__restrict__ flag,
-                                                             int32_t *__restrict__ slot, int32_t *__restrict__ total)
+// pairk[slot] = convolve2d(akerns[a1], akerns[a2]) for every pair that occurs (one work-group per pair at a time)
+__global__ void aw_pair_kernel(int64_t A, int S, const double2 *__restrict__ akerns, const int32_t *__restrict__ pairlist,
+                               const int32_t *__restrict__ counters, int32_t cap, double2 *__restrict__ pairk)
 {
-    __shared__ int32_t part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (m + 1023) / 1024;
-    const int64_t lo = tid * per, hi = min(lo + per, m);
-    int s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += flag[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < 1024; ++i) {
-            int t = part[i];
-            part[i] = acc;
-            acc += t;
+    extern __shared__ double2 sm[];
+    const int npairs = min(counters[0], cap);
+    double2 *la = sm, *lb = sm + S * S;
+    for (int s = blockIdx.x; s < npairs; s += gridDim.x) {
+        const int64_t pq = pairlist[s];
+        const int64_t p = pq / A, q = pq - p * A;
+        __syncthreads();
+        for (int t = threadIdx.x; t < S * S; t += blockDim.x) {
+            la[t] = akerns[p * S * S + t];
+            lb[t] = akerns[q * S * S + t];
         }
-        *total = acc;
-    }
-    __syncthreads();
-    int acc = part[tid];
-    for (int64_t i = lo; i < hi; ++i) {
-        slot[i] = flag[i] ? acc : -1;
-        acc += flag[i];
+        __syncthreads();
+        conv_same_T(la, lb, S, pairk + (size_t)s * S * S, false);
     }
 }
 
-// akern[slot] = convolve2d(akerns[a1], akerns[a2]) for every used pair (one work-group per pair index)
-__global__ void aw_pair_kernel(int64_t A, int S, const double2 *__restrict__ akerns, const int32_t *__restrict__ slot,
-                               double2 *__restrict__ pairk)
+// ---- 2. keys.  key = pair slot << 30 | w-kernel slice (wslice < 2^30, pair slot < 2^31).
+// cache: insert into an open-addressing table (64-bit CAS); the first to insert a key numbers it.
+//   kid[k]  : index of the visibility's kernel in this batch's table, or -1 (dropped: index out of range)
+//   ok[k]   : 0 / -1, handed to the binning pre-pass as the "w-plane" of a one-plane table (-1 is dropped and counted)
+//   ukey[id]: the key of table entry id;  counters[1] = entries so far
+__global__ void aw_keys_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int32_t Q, int64_t A,
+                               const double *__restrict__ u, const double *__restrict__ v, int64_t stride,
+                               const int64_t *__restrict__ wbin, const int64_t *__restrict__ a1,
+                               const int64_t *__restrict__ a2, const int32_t *__restrict__ slot, int cache,
+                               unsigned long long *__restrict__ htab, int32_t *__restrict__ hid, uint32_t hmask,
+                               int32_t *__restrict__ kid, int64_t *__restrict__ ok, unsigned long long *__restrict__ ukey,
+                               int32_t *__restrict__ counters, int32_t cap)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t wb = wbin[k], p = a1[k], q = a2[k];
+        const double pu = u[k * stride], pv = v[k * stride];
+        int32_t ps = -1;
+        if (p >= 0 && p < A && q >= 0 && q < A) ps = slot[p * A + q];
+        // the reference would index out of range; such a visibility contributes nothing and is counted
+        const bool bad = wb < 0 || wb >= W || ps < 0 || !(pu == pu) || !(pv == pv);
+        int32_t id = -1;
+        if (!bad) {
+            int64_t x, y;
+            int32_t xf, yf;
+            frac_coord_dev(Wd, Q, pu, &x, &xf);
+            frac_coord_dev(H, Q, pv, &y, &yf);
+            const unsigned long long key = ((unsigned long long)ps << 30) | (unsigned long long)((wb * Q + yf) * Q + xf);
+            if (!cache) {
+                id = (int32_t)k;
+                ukey[k] = key;
+            } else {
+                uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & hmask;
+                for (;;) {
+                    const unsigned long long cur = __hip_atomic_load(&htab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == key) break;
+                    if (cur == AW_EMPTY) {
+                        const unsigned long long old = atomicCAS(&htab[h], AW_EMPTY, key);
+                        if (old == AW_EMPTY) {  // ours: number it
+                            const int32_t nid = atomicAdd(&counters[1], 1);
+                            if (nid < cap) ukey[nid] = key;
+                            __hip_atomic_store(&hid[h], nid < cap ? nid : -3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        if (old == key) break;
+                    }
+                    h = (h + 1) & hmask;  // (the table has at least twice as many slots as there are keys)
+                }
+                id = -(int32_t)h - 16;  // resolved by aw_kid_kernel once every number has been handed out
+            }
+        }
+        kid[k] = id;
+        ok[k] = bad ? -1 : 0;
+    }
+}
+
+// second half of the cached form: hash slot -> number (a separate launch, so that every number is visible)
+__global__ void aw_kid_kernel(int64_t n, const int32_t *__restrict__ hid, int32_t *__restrict__ kid, int64_t *__restrict__ ok)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t c = kid[k];
+        if (c <= -16) {
+            const int32_t id = hid[-(c + 16)];
+            kid[k] = id;
+            if (id < 0) ok[k] = -1;  // (cannot happen: the table holds as many kernels as the batch has visibilities)
+        }
+    }
+}
+
+// ---- 3. kernels of the distinct keys: table[id] = conj(convolve2d(pairk[pair], wkerns[wslice]))
+// generic support: one work-group per key at a time
+__global__ void aw_build_generic_kernel(int S, const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
+                                        const unsigned long long *__restrict__ ukey, const int32_t *__restrict__ counters,
+                                        int which, int32_t fixed_count, int32_t cap, double2 *__restrict__ table)
 {
     extern __shared__ double2 sm[];
-    const int64_t pq = blockIdx.x;
-    const int32_t s = slot[pq];
-    if (s < 0) return;
-    const int64_t p = pq / A, q = pq - p * A;
+    const int nk = min(which >= 0 ? counters[which] : fixed_count, cap);
     double2 *la = sm, *lb = sm + S * S;
-    for (int t = threadIdx.x; t < S * S; t += blockDim.x) {
-        la[t] = akerns[p * S * S + t];
-        lb[t] = akerns[q * S * S + t];
+    for (int id = blockIdx.x; id < nk; id += gridDim.x) {
+        const unsigned long long key = ukey[id];
+        const double2 *pk = pairk + (size_t)(key >> 30) * S * S;
+        const double2 *wk = wkerns + (size_t)(key & 0x3fffffffull) * S * S;
+        __syncthreads();
+        for (int t = threadIdx.x; t < S * S; t += blockDim.x) {
+            la[t] = pk[t];
+            lb[t] = wk[t];
+        }
+        __syncthreads();
+        conv_same_T(la, lb, S, table + (size_t)id * S * S, true);
     }
-    __syncthreads();
-    conv_same_T(la, lb, S, pairk + (size_t)s * S * S, false);
 }
 
-// kperv[k] = conj(convolve2d(pairk[pair_k], wkerns[wbin_k, yf_k, xf_k]))  (one work-group per visibility)
-__global__ void aw_vis_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int32_t Q, int S, int64_t A,
-                              const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
-                              const int32_t *__restrict__ slot, const double *__restrict__ u,
-                              const double *__restrict__ v, int64_t stride, const int64_t *__restrict__ wbin,
-                              const int64_t *__restrict__ a1, const int64_t *__restrict__ a2,
-                              double2 *__restrict__ kperv, int32_t *__restrict__ scalars)
-{
-    extern __shared__ double2 sm[];
-    const int64_t k = blockIdx.x;
-    if (k >= n) return;
-    double2 *out = kperv + (size_t)k * S * S;
-    const int64_t wb = wbin[k], p = a1[k], q = a2[k];
-    const double pu = u[k * stride], pv = v[k * stride];
-    const bool bad = wb < 0 || wb >= W || p < 0 || p >= A || q < 0 || q >= A || !(pu == pu) || !(pv == pv);
-    if (bad) {  // the reference would index out of range; contribute nothing and count it
-        for (int t = threadIdx.x; t < S * S; t += blockDim.x) out[t] = make_double2(0.0, 0.0);
-        if (threadIdx.x == 0 && (pu == pu) && (pv == pv)) atomicAdd(&scalars[1], 1);
-        return;
-    }
-    int64_t x, y;
-    int32_t xf, yf;
-    frac_coord_dev(Wd, Q, pu, &x, &xf);
-    frac_coord_dev(H, Q, pv, &y, &yf);
-    const double2 *wk = wkerns + ((size_t)(wb * Q + yf) * Q + xf) * S * S;
-    const double2 *pk = pairk + (size_t)slot[p * A + q] * S * S;
-    double2 *la = sm, *lb = sm + S * S;
-    for (int t = threadIdx.x; t < S * S; t += blockDim.x) {
-        la[t] = pk[t];
-        lb[t] = wk[t];
-    }
-    __syncthreads();
-    conv_same_T(la, lb, S, out, true);
-}
-
-
-// The same per-visibility kernels for a compile-time support, organised for the vector ALU: a wave takes four
-// visibilities at a time, lane = (visibility v, column x), and every lane keeps out[y][x] for all S rows y in
-// registers.  For each row i of the pair kernel the lane holds a[i][0..S) in registers (fetched one row ahead)
-// and, for every y whose w-kernel row r = y - i + c exists, adds sum_j a[i][j] * b[r][x + c - j]; b comes
-// from an LDS copy of the w-kernel slice padded with c zero columns on both sides, so the inner loops have
-// no bounds logic and skip whole rows only (uniformly).  One LDS read and four FMAs per complex product
-// against two reads, the FMAs and ~8 address/loop instructions in the generic kernel above.
+// Compile-time support, organised for the fp64 vector ALU.  A wave builds four kernels at a time: lane = (kernel q,
+// column x), and the lane keeps out[y][x] for all S rows y in registers.  The loop nest is ordered so that one LDS
+// read feeds many FMAs: for each column j of the pair kernel the lane fetches the S values a[i][j] (all i) and the
+// S values b[r][x + c - j] (all r) - 2 S reads - and then performs the S^2 - c(c+1) products of the pairs (i, r)
+// whose output row y = r + i - c exists, four FMAs each, from registers: 30 reads per 169 complex products at
+// 15 x 15.  b comes from an LDS copy of the w-kernel slice whose rows are followed by c zeros (row pitch S + c, c
+// zeros in front of row 0), so a column index of -c .. S-1+c needs no bounds logic.
 template <int S>
-__global__ void __launch_bounds__(256) aw_vis_rows_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int32_t Q,
-                                                          int64_t A, const double2 *__restrict__ wkerns,
-                                                          const double2 *__restrict__ pairk,
-                                                          const int32_t *__restrict__ slot,
-                                                          const double *__restrict__ u, const double *__restrict__ v,
-                                                          int64_t stride, const int64_t *__restrict__ wbin,
-                                                          const int64_t *__restrict__ a1,
-                                                          const int64_t *__restrict__ a2, double2 *__restrict__ kperv,
-                                                          int32_t *__restrict__ scalars)
+__global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
+                                                       const unsigned long long *__restrict__ ukey,
+                                                       const int32_t *__restrict__ counters, int which, int32_t fixed_count,
+                                                       int32_t cap, double2 *__restrict__ table)
 {
-    constexpr int C = S / 2, PW = S + 2 * C, S2 = S * S;
-    static_assert(S <= 16, "one 16-lane row per visibility");
+    constexpr int C = S / 2, PB = S + C, S2 = S * S, BSZ = C + S * PB;  // padded slice: C zeros, then rows of S values + C zeros
+    static_assert(S <= 16, "one 16-lane row per kernel");
     extern __shared__ double2 sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int v4 = lane >> 4, x = lane & 15;
-    double2 *bp = sm + (size_t)(wave * 4 + v4) * S * PW;  // this visibility's padded w-kernel slice
-    // pair-kernel rows pass through a two-deep LDS ring (one element per lane and row, fetched one row ahead)
-    double2 *aring = sm + (size_t)16 * S * PW + (size_t)wave * 2 * 64;
-    const int64_t groups = (n + 3) / 4;
+    const int q = lane >> 4, x = lane & 15;
+    double2 *abuf = sm + (size_t)(wave * 4 + q) * (S2 + BSZ);  // this kernel's pair kernel ...
+    double2 *bbuf = abuf + S2;                                  // ... and padded w-kernel slice
+    const int nk = min(which >= 0 ? counters[which] : fixed_count, cap);
+    // the zeros of the padded slices are written once
+    for (int e = x; e < BSZ; e += 16) {
+        const int pos = e - C, col = pos >= 0 ? pos % PB : -1;
+        if (pos < 0 || col >= S) bbuf[e] = make_double2(0.0, 0.0);
+    }
+    const int64_t groups = ((int64_t)nk + 3) / 4;
     for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
-        const int64_t k = grp * 4 + v4;
-        const bool have = k < n;
-        int64_t wb = 0, p = 0, q = 0;
-        double pu = 0.0, pv = 0.0;
-        if (have) {
-            wb = wbin[k];
-            p = a1[k];
-            q = a2[k];
-            pu = u[k * stride];
-            pv = v[k * stride];
-        }
-        const bool bad = wb < 0 || wb >= W || p < 0 || p >= A || q < 0 || q >= A || !(pu == pu) || !(pv == pv);
-        const bool live = have && !bad;
-        int64_t cx = 0, cy = 0;
-        int32_t xf = 0, yf = 0;
-        if (live) {
-            frac_coord_dev(Wd, Q, pu, &cx, &xf);
-            frac_coord_dev(H, Q, pv, &cy, &yf);
-        }
-        const double2 *wk = wkerns + (live ? ((size_t)(wb * Q + yf) * Q + xf) * S2 : 0);
-        const double2 *pk = pairk + (live ? (size_t)slot[p * A + q] * S2 : 0);
-        // padded copy of the slice: row r, padded column pc holds b[r][pc - C]
+        const int64_t id = grp * 4 + q;
+        const bool have = id < nk;
+        const unsigned long long key = have ? ukey[id] : 0ull;
+        const double2 *pk = pairk + (have ? (size_t)(key >> 30) * S2 : 0);
+        const double2 *wk = wkerns + (have ? (size_t)(key & 0x3fffffffull) * S2 : 0);
         __builtin_amdgcn_wave_barrier();  // (the previous group's reads of this LDS region are done: same wave)
         {   // all of the lane's loads first, then its LDS stores (a load-store loop would pay the memory latency per trip)
-            constexpr int NE = (S * PW + 15) / 16;
-            double2 stage[NE];
+            constexpr int NE = (S2 + 15) / 16;
+            double2 sa[NE], sb[NE];
 #pragma unroll
             for (int t = 0; t < NE; ++t) {
-                const int e = x + 16 * t;
-                const int r = e / PW, pc = e - r * PW, cc = pc - C;
-                stage[t] = (live && e < S * PW && cc >= 0 && cc < S) ? wk[r * S + cc] : make_double2(0.0, 0.0);
+                const int e = min(x + 16 * t, S2 - 1);
+                sa[t] = pk[e];
+                sb[t] = wk[e];
             }
 #pragma unroll
             for (int t = 0; t < NE; ++t) {
                 const int e = x + 16 * t;
-                if (e < S * PW) bp[e] = stage[t];
+                if (e < S2) {
+                    abuf[e] = sa[t];
+                    bbuf[C + (e / S) * PB + (e % S)] = sb[t];
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // acc[r] belongs to output row y = r + i - C while pair-kernel row i is being applied (it meets w-kernel
-        // row r there); after each i the array moves down by one and the row that has just received its last
-        // contribution leaves.  So every index below is a compile-time constant.
         double2 acc[S];
 #pragma unroll
-        for (int r = 0; r < S; ++r) acc[r] = make_double2(0.0, 0.0);
-        double2 *out = kperv + (size_t)(have ? k : 0) * S2 + (size_t)x * S;  // out[x * S + y]: comes out transposed
-        const bool store = have && x < S;
-        double2 arow[S], b0[S], b1[S];  // b0 / b1: w-kernel row r for even / odd r, one fetched ahead
-        const int xa = x < S ? x : S - 1;
-        double2 anext = pk[xa];  // this lane's element of row 0
-        for (int i = 0; i < S; ++i) {
-            aring[(i & 1) * 64 + lane] = anext;
-            if (i + 1 < S) anext = pk[(i + 1) * S + xa];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int y = 0; y < S; ++y) acc[y] = make_double2(0.0, 0.0);
+        const int xc = x < S ? x : S - 1;  // (the 16th lane of a row repeats the 15th: its results are not stored)
+        for (int j = 0; j < S; ++j) {
+            double2 acol[S], bcol[S];
+            const double2 *bp = bbuf + C + (xc + C - j);  // b[r][xc + C - j] = bp[r * PB]
 #pragma unroll
-            for (int j = 0; j < S; ++j) arow[j] = aring[(i & 1) * 64 + v4 * 16 + j];  // a[i][j] of this lane's visibility
-            const int rlo = max(0, C - i), rhi = min(S - 1, S - 1 + C - i);  // rows r whose y = r + i - C exists
-            {
-                const double2 *brow = bp + rlo * PW + (x + 2 * C);  // b[r][x + C - j] = brow[-j]
-                if (rlo & 1) {
+            for (int i = 0; i < S; ++i) acol[i] = abuf[i * S + j];
 #pragma unroll
-                    for (int j = 0; j < S; ++j) b1[j] = brow[-j];
-                } else {
+            for (int r = 0; r < S; ++r) bcol[r] = bp[r * PB];
 #pragma unroll
-                    for (int j = 0; j < S; ++j) b0[j] = brow[-j];
+            for (int i = 0; i < S; ++i) {
+#pragma unroll
+                for (int r = 0; r < S; ++r) {
+                    const int y = r + i - C;
+                    if (y < 0 || y >= S) continue;  // (compile time)
+                    acc[y].x = fma(acol[i].x, bcol[r].x, acc[y].x);
+                    acc[y].x = fma(-acol[i].y, bcol[r].y, acc[y].x);
+                    acc[y].y = fma(acol[i].x, bcol[r].y, acc[y].y);
+                    acc[y].y = fma(acol[i].y, bcol[r].x, acc[y].y);
                 }
             }
-#pragma unroll
-            for (int r = 0; r < S; ++r) {
-                if (r < rlo || r > rhi) continue;  // uniform
-                double2(&bc)[S] = (r & 1) ? b1 : b0;
-                double2(&bn)[S] = (r & 1) ? b0 : b1;
-                if (r + 1 <= rhi) {
-                    const double2 *brow = bp + (r + 1) * PW + (x + 2 * C);
-#pragma unroll
-                    for (int j = 0; j < S; ++j) bn[j] = brow[-j];
-                }
-                // four independent chains (one FMA each per product): with one wave per SIMD nothing else hides
-                // the FMA latency
-                double pr = 0.0, qr = 0.0, pi = 0.0, qi = 0.0;
-#pragma unroll
-                for (int j = 0; j < S; ++j) {
-                    pr = fma(arow[j].x, bc[j].x, pr);
-                    qr = fma(arow[j].y, bc[j].y, qr);
-                    pi = fma(arow[j].x, bc[j].y, pi);
-                    qi = fma(arow[j].y, bc[j].x, qi);
-                }
-                acc[r].x += pr - qr;
-                acc[r].y += pi + qi;
-            }
-            // acc[0] is row y = i - C: complete when that exists
-            if (i >= C && store) out[i - C] = live ? make_double2(acc[0].x, -acc[0].y) : make_double2(0.0, 0.0);
-#pragma unroll
-            for (int r = 0; r + 1 < S; ++r) acc[r] = acc[r + 1];
-            acc[S - 1] = make_double2(0.0, 0.0);
         }
-        // after the shift that followed i = S-1, acc[r] is row y = r + S - C
-        if (store) {
+        if (have && x < S) {  // out[x * S + y]: the result comes out transposed, and is conjugated
+            double2 *out = table + (size_t)id * S2 + (size_t)x * S;
 #pragma unroll
-            for (int r = 0; r + S - C < S; ++r)
-                out[r + S - C] = live ? make_double2(acc[r].x, -acc[r].y) : make_double2(0.0, 0.0);
-            if (bad && x == 0 && (pu == pu) && (pv == pv)) atomicAdd(&scalars[1], 1);
+            for (int y = 0; y < S; ++y) out[y] = make_double2(acc[y].x, -acc[y].y);
         }
     }
 }
+
+// records come out of the binning pre-pass with kslice = the visibility's index: replace it by its kernel's
+__global__ void aw_relabel_kernel(VisRec *__restrict__ recs, const int32_t *__restrict__ nrec, const int32_t *__restrict__ kid,
+                                  int32_t nvis)
+{
+    const int n = *nrec;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t o = recs[i].orig;
+        recs[i].kslice = (uint32_t)o < (uint32_t)nvis ? max(kid[o], 0) : 0;
+    }
+}
+
+// [1] += [0]: the drops of one batch's binning join the call's total; [28] += the batch's distinct kernels
+__global__ void aw_account_kernel(int32_t *__restrict__ scalars, const int32_t *__restrict__ counters, int cache, int32_t m)
+{
+    scalars[1] += scalars[0];
+    scalars[28] += cache ? counters[1] : m;
+    scalars[29] += m;
+}
+__global__ void aw_finish_kernel(int32_t *__restrict__ scalars) { scalars[0] = scalars[1]; }
 
 }  // namespace gridhip
 
 using namespace gridhip;
 
+namespace {
+template <int S>
+int launch_build(gridhip_ctx *ctx, const double2 *wk, const double2 *pairk, const unsigned long long *ukey,
+                 const int32_t *counters, int which, int32_t fixed, int32_t cap, double2 *table)
+{
+    constexpr int C = S / 2, PB = S + C, BSZ = C + S * PB;
+    const size_t lds = (size_t)16 * (S * S + BSZ) * sizeof(double2);
+    GH_CHECK(raise_lds(ctx, aw_build_kernel<S>));
+    // one work-group (four waves, one per SIMD) per CU; the loop strides over the keys
+    hipLaunchKernelGGL(aw_build_kernel<S>, dim3(ctx->num_cu), dim3(256), lds, ctx->stream, wk, pairk, ukey, counters, which,
+                       fixed, cap, table);
+    return GRIDHIP_OK;
+}
+}  // namespace
+
 extern "C" {
 
-// Device pointers; asynchronous except for scratch allocation and one read-back of the pair count.
+// Device pointers; asynchronous (nothing is read back; scratch grows on first use).
 int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W, int64_t Q,
                        int64_t S, int64_t A, const double *wkerns, const double *akerns, const double *u,
                        const double *v, int64_t uv_stride, const int64_t *wbin, const int64_t *a1,
@@ -280,84 +307,136 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
     if (H <= 0 || Wd <= 0 || n < 0 || W <= 0 || Q <= 0 || S <= 0 || A <= 0 || uv_stride < 1 || !grid || !wkerns ||
         !akerns || (n > 0 && (!u || !v || !wbin || !a1 || !a2 || !vis)))
         return fail(ctx, GRIDHIP_EINVAL, "bad argument");
-    if (S > 63 || A > 46340 || n > (int64_t)0x7fffff00) return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside aw limits");
+    if (S > 63 || A > 46340 || n > (int64_t)0x7fffff00 || W * Q * Q >= ((int64_t)1 << 30))
+        return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside aw limits");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16 * sizeof(int32_t), ctx->stream));
+    // [0] dropped, [1] dropped so far (batches), [2] errors, [28] distinct kernels built, [29] visibilities keyed
+    GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(int32_t), ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 28, 0, 2 * sizeof(int32_t), ctx->stream));
     if (n == 0) return GRIDHIP_OK;
     const size_t S2 = (size_t)S * S, pairs = (size_t)A * A;
-    const size_t lds = 2 * S2 * sizeof(double2);
+    const int cache = ctx->opt.aw_cache != 0;
+    const int64_t batch = n < ((int64_t)1 << 22) ? n : ((int64_t)1 << 22);  // 4M kernels x 3.6 KB = 15 GB at 15x15
+    const int32_t pair_cap = (int32_t)(pairs < (size_t)n ? pairs : (size_t)n);
+    uint32_t hslots = 1024;
+    while (hslots < 2 * (uint64_t)batch) hslots <<= 1;
 
+    // ---- scratch (grows on first use; laid out in one workspace)
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_slot = 0, o_plist = o_slot + al(pairs * 4), o_cnt = o_plist + al((size_t)pair_cap * 4),
+                 o_pairk = o_cnt + al(64), o_htab = o_pairk + al((size_t)pair_cap * S2 * 16),
+                 o_hid = o_htab + al((size_t)hslots * 8), o_kid = o_hid + al((size_t)hslots * 4),
+                 o_ok = o_kid + al((size_t)batch * 4), o_ukey = o_ok + al((size_t)batch * 8),
+                 o_table = o_ukey + al((size_t)batch * 8), total = o_table + al((size_t)batch * S2 * 16);
+    GH_CHECK(ws_reserve(ctx, ctx->aw, total));
+    char *base = (char *)ctx->aw.ptr;
+    int32_t *slot = (int32_t *)(base + o_slot), *pairlist = (int32_t *)(base + o_plist), *counters = (int32_t *)(base + o_cnt);
+    double2 *pairk = (double2 *)(base + o_pairk), *table = (double2 *)(base + o_table);
+    unsigned long long *htab = (unsigned long long *)(base + o_htab), *ukey = (unsigned long long *)(base + o_ukey);
+    int32_t *hid = (int32_t *)(base + o_hid), *kid = (int32_t *)(base + o_kid);
+    int64_t *ok = (int64_t *)(base + o_ok);
+
+    // geometry of the gridding step (one plane: `ok` stands in for wbin; every slice is private to its key)
+    Prep p;
+    {
+        const int64_t keep_w = ctx->opt.wgroups;
+        ctx->opt.wgroups = 1;  // the table is read once per run: nothing for an L2 to keep
+        Geom g;
+        int block;
+        size_t lds;
+        int rc = make_geom(ctx, H, Wd, 1, Q, S, S, batch, &g, &block, &lds);
+        ctx->opt.wgroups = keep_w;
+        GH_CHECK(rc);
+        g.per_vis = 1;
+        g.nslices = (int32_t)batch;  // table capacity: a record's kslice is brought below it
+        p.g = g;
+        p.block = block;
+        p.lds = lds;
+        p.nrec = batch;
+        p.sorted = ctx->opt.sort != 2 && sorted_plan(ctx, p.g, p.block, &p.nkeys, &p.batch, &p.lds_sorted);
+        if (p.sorted) p.g.chunk = p.batch;
+    }
+    GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(p.g)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)batch * sizeof(VisRec)));
+
+    mark(ctx, 0);
     // ---- antenna-pair kernels
-    void *dflag = nullptr, *dslot = nullptr, *dpairk = nullptr, *dkperv = nullptr;
-    int rc = GRIDHIP_OK;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(ctx->stream);
-        if (dflag) (void)hipFree(dflag);
-        if (dslot) (void)hipFree(dslot);
-        if (dpairk) (void)hipFree(dpairk);
-        if (dkperv) (void)hipFree(dkperv);
-    };
-#define AW_HIP(call)                                                                                       \
-    do {                                                                                                   \
-        hipError_t e__ = (call);                                                                           \
-        if (e__ != hipSuccess) {                                                                           \
-            rc = fail(ctx, e__ == hipErrorOutOfMemory ? GRIDHIP_ENOMEM : GRIDHIP_EHIP, "%s failed: %s", #call, \
-                      hipGetErrorString(e__));                                                             \
-            cleanup();                                                                                     \
-            return rc;                                                                                     \
-        }                                                                                                  \
-    } while (0)
-    AW_HIP(hipMalloc(&dflag, pairs * 4 + 16));
-    AW_HIP(hipMalloc(&dslot, pairs * 4));
-    AW_HIP(hipMemsetAsync(dflag, 0, pairs * 4 + 16, ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(slot, 0xff, pairs * 4, ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(counters, 0, 64, ctx->stream));
     int64_t blocks = (n + 255) / 256;
     if (blocks > ctx->num_cu * 8) blocks = ctx->num_cu * 8;
-    hipLaunchKernelGGL(aw_mark_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n, A, a1, a2,
-                       (int32_t *)dflag);
-    int32_t *dtotal = (int32_t *)dflag + pairs;
-    hipLaunchKernelGGL(aw_scan_pairs_kernel, dim3(1), dim3(1024), 0, ctx->stream, (int64_t)pairs,
-                       (const int32_t *)dflag, (int32_t *)dslot, dtotal);
-    int32_t used = 0;
-    AW_HIP(hipMemcpyAsync(&used, dtotal, 4, hipMemcpyDeviceToHost, ctx->stream));
-    AW_HIP(hipStreamSynchronize(ctx->stream));
-    AW_HIP(hipMalloc(&dpairk, (size_t)(used > 0 ? used : 1) * S2 * 16));
-    hipLaunchKernelGGL(aw_pair_kernel, dim3((unsigned)pairs), dim3(256), lds, ctx->stream, A, (int)S,
-                       (const double2 *)akerns, (const int32_t *)dslot, (double2 *)dpairk);
+    hipLaunchKernelGGL(aw_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n, A, a1, a2, slot, pairlist,
+                       counters, pair_cap);
+    {
+        int pb = pair_cap < ctx->num_cu * 8 ? pair_cap : ctx->num_cu * 8;
+        hipLaunchKernelGGL(aw_pair_kernel, dim3((unsigned)(pb > 0 ? pb : 1)), dim3(256), 2 * S2 * sizeof(double2), ctx->stream,
+                           A, (int)S, (const double2 *)akerns, pairlist, counters, pair_cap, pairk);
+    }
+    GH_CHECK_HIP(ctx, hipGetLastError());
 
-    // ---- per-visibility kernels + gridding, in batches
-    const int64_t batch = n < (1 << 21) ? n : (1 << 21);  // 2M x 3.6 KB = 7.5 GB at 15x15
-    AW_HIP(hipMalloc(&dkperv, (size_t)batch * S2 * 16));
+    // ---- per batch: keys -> distinct kernels -> binning -> tile gridder
     for (int64_t lo = 0; lo < n; lo += batch) {
         const int64_t m = n - lo < batch ? n - lo : batch;
-        if (S == 15) {
-            constexpr int S_ = 15;
-            const size_t rows_lds = ((size_t)16 * S_ * (S_ + 2 * (S_ / 2)) + 4 * 2 * 64) * sizeof(double2);  // 16 padded slices + row rings
-            if (!(ctx->attr_mask & 4u)) {
-                AW_HIP(hipFuncSetAttribute((const void *)aw_vis_rows_kernel<S_>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
-                ctx->attr_mask |= 4u;
-            }
-            int64_t rblocks = (m + 15) / 16;
-            if (rblocks > ctx->num_cu) rblocks = ctx->num_cu;
-            hipLaunchKernelGGL(aw_vis_rows_kernel<S_>, dim3((unsigned)rblocks), dim3(256), rows_lds, ctx->stream, H, Wd,
-                               m, W, (int32_t)Q, A, (const double2 *)wkerns, (const double2 *)dpairk,
-                               (const int32_t *)dslot, u + lo * uv_stride, v + lo * uv_stride, uv_stride, wbin + lo,
-                               a1 + lo, a2 + lo, (double2 *)dkperv, ctx->d_scalars);
-        } else
-        hipLaunchKernelGGL(aw_vis_kernel, dim3((unsigned)m), dim3(256), lds, ctx->stream, H, Wd, m, W, (int32_t)Q,
-                           (int)S, A, (const double2 *)wkerns, (const double2 *)dpairk, (const int32_t *)dslot,
-                           u + lo * uv_stride, v + lo * uv_stride, uv_stride, wbin + lo, a1 + lo, a2 + lo,
-                           (double2 *)dkperv, ctx->d_scalars);
-        AW_HIP(hipGetLastError());
-        rc = grid_per_vis_kernels(ctx, H, Wd, grid, m, Q, S, S, (const double *)dkperv, u + lo * uv_stride,
-                                  v + lo * uv_stride, uv_stride, vis + 2 * lo);
-        if (rc != GRIDHIP_OK) {
-            cleanup();
-            return rc;
+        const double *bu = u + lo * uv_stride, *bv = v + lo * uv_stride;
+        if (cache) {
+            GH_CHECK_HIP(ctx, hipMemsetAsync(htab, 0xff, (size_t)hslots * 8, ctx->stream));
+            GH_CHECK_HIP(ctx, hipMemsetAsync(counters + 1, 0, 4, ctx->stream));
         }
+        int64_t kb = (m + 255) / 256;
+        if (kb > ctx->num_cu * 8) kb = ctx->num_cu * 8;
+        hipLaunchKernelGGL(aw_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, H, Wd, m, W, (int32_t)Q, A, bu, bv,
+                           uv_stride, wbin + lo, a1 + lo, a2 + lo, slot, cache, htab, hid, hslots - 1, kid, ok, ukey,
+                           counters, (int32_t)batch);
+        if (cache)
+            hipLaunchKernelGGL(aw_kid_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, m, hid, kid, ok);
+        const int which = cache ? 1 : -1;
+        switch (S) {
+#define AW_CASE(S_) \
+    case S_: GH_CHECK(launch_build<S_>(ctx, (const double2 *)wkerns, pairk, ukey, counters, which, (int32_t)m, (int32_t)batch, table)); break;
+            AW_CASE(5) AW_CASE(7) AW_CASE(9) AW_CASE(11) AW_CASE(13) AW_CASE(15)
+#undef AW_CASE
+            default: {
+                int gb = (int)(m < ctx->num_cu * 8 ? m : ctx->num_cu * 8);
+                hipLaunchKernelGGL(aw_build_generic_kernel, dim3((unsigned)gb), dim3(256), 2 * S2 * sizeof(double2), ctx->stream,
+                                   (int)S, (const double2 *)wkerns, pairk, ukey, counters, which, (int32_t)m, (int32_t)batch,
+                                   table);
+            }
+        }
+        GH_CHECK_HIP(ctx, hipGetLastError());
+        mark(ctx, 1);
+        // gridding: the pre-pass drops the visibilities whose `ok` is -1 (counted), the tile kernel reads the table
+        p.g.nvis = (int32_t)m;
+        GH_CHECK(launch_bin(ctx, p.g, m, bu, bv, uv_stride, ok));
+        Tables t = tables_of(ctx, p.g);
+        {
+            int rb = (int)((m + 255) / 256);
+            if (rb > ctx->num_cu * 8) rb = ctx->num_cu * 8;
+            hipLaunchKernelGGL(aw_relabel_kernel, dim3((unsigned)rb), dim3(256), 0, ctx->stream, (VisRec *)ctx->recs.ptr,
+                               t.bin_start + p.g.nbins, kid, (int32_t)m);
+        }
+        if (p.sorted)
+            GH_CHECK(launch_tile_grid_sorted(ctx, p.g, p.block, p.lds_sorted, p.nkeys, p.batch, m, (const double *)table,
+                                             vis + 2 * lo, grid, false));
+        else
+            GH_CHECK(launch_tile_grid(ctx, p.g, p.block, p.lds, m, (const double *)table, vis + 2 * lo, grid));
+        hipLaunchKernelGGL(aw_account_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scalars, counters, cache, (int32_t)m);
+        mark(ctx, 2);
     }
-#undef AW_HIP
-    cleanup();
+    hipLaunchKernelGGL(aw_finish_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scalars);
+    GH_CHECK_HIP(ctx, hipGetLastError());
+    return GRIDHIP_OK;
+}
+
+// What the last gridhip_awgrid*_dev call did (synchronises): visibilities keyed, distinct kernels built.
+int gridhip_aw_last_stats(gridhip_ctx *ctx, int64_t *vis_keyed, int64_t *kernels_built)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t h[2] = {0, 0};
+    GH_CHECK_HIP(ctx, hipMemcpyAsync(h, ctx->d_scalars + 28, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (kernels_built) *kernels_built = h[0];
+    if (vis_keyed) *vis_keyed = h[1];
     return GRIDHIP_OK;
 }
 

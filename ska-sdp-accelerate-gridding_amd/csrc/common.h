@@ -73,6 +73,7 @@ struct gridhip_ctx {
     gridhip::Workspace recs_tmp;   // coarse-binned records between the two scatter levels of the pre-pass (bin.hip)
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
     gridhip::Workspace ktab;       // kernel table cut into zero-padded square parts (sub-footprints, api.hip)
+    gridhip::Workspace aw;         // aw gridders: pair slots, pair kernels, key hash table, table of distinct kernels
     int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=aw drops, [2]=errors, [4..19] work queues,
                                    // [20..27] clock stamps of the last sorted tile kernel, [32..] profile
     int num_cu = 256;
@@ -113,14 +114,23 @@ int fail(gridhip_ctx *ctx, int code, const char *fmt, ...);
 
 int ws_reserve(gridhip_ctx *ctx, Workspace &ws, size_t bytes);
 
+// HIP events of a timed call: i = 0: it starts, 1: its pre-pass is enqueued, 2: its dominant kernel is enqueued (the
+// call is then readable with gridhip_timing)
+static inline void mark(gridhip_ctx *ctx, int i)
+{
+    if (!ctx->timing) return;
+    if (i == 0) ctx->ev_open = true;
+    if (!ctx->ev_open) return;
+    (void)hipEventRecord(ctx->ev[(ctx->ev_calls % gridhip_ctx::EV_RING) * 3 + i], ctx->stream);
+    if (i == 2) {
+        ctx->ev_open = false;
+        ++ctx->ev_calls;
+    }
+}
+
 // geometry / option resolution (host)
 int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh,
               int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes);
-// grids n visibilities whose kernels are kperv[k][gh][gw] (device pointers, stream-ordered)
-int grid_per_vis_kernels(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t Q,
-                         int64_t gh, int64_t gw, const double *kperv, const double *u, const double *v,
-                         int64_t uv_stride, const double *vis);
-
 // ---- device-side coordinate math ---------------------------------------------------------
 // frac_coord of src/Gridding.hs:126-140, bit-for-bit with the oracle: contraction is switched
 // off for this block so `halfn + p*n` stays a rounded multiply followed by a rounded add

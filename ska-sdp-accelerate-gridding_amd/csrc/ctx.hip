@@ -240,7 +240,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     fft_release(ctx);
-    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp, &ctx->recs_raw, &ctx->ktab};
+    Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp, &ctx->recs_raw, &ctx->ktab, &ctx->aw};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);

@@ -47,7 +47,12 @@ struct SortedItem {
     int32_t valid, tile, grp, staged;
 };
 
-template <int S, bool DEGRID, int ABL = 0>
+// AW (aw gridders, awgrid.hip): a record's kslice is the index of its de-duplicated (a1, a2, wbin, yf, xf) kernel in a
+// table built for this call - arbitrary 31-bit numbers, far more of them than a histogram holds.  The counting sort
+// then orders by kslice mod nkeys (equal kernels still end up next to each other unless two of them share a
+// residue) and the sorted list carries the kslice itself in place of `orig`, which gridding does not need; a run
+// is a stretch of equal kslice.
+template <int S, bool DEGRID, int ABL = 0, bool AW = false>
 __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
                                                                 const int32_t *__restrict__ work_start,
@@ -153,6 +158,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             for (int q = 0; q < 8; ++q) {
                 bool off;  // (a stale record is counted by neither pass)
                 key[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1), g, &off).kslice - first_slice;
+                if (AW) key[q] = (int)((unsigned)key[q] % (unsigned)nkeys);
                 if (off) key[q] = -1;
             }
 #pragma unroll
@@ -199,7 +205,8 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (r0 + q * 64 >= cnt) break;
-                const int key = rec[q].kslice - first_slice;
+                int key = rec[q].kslice - first_slice;
+                if (AW) key = (int)((unsigned)key % (unsigned)nkeys);
                 if (off[q] || (unsigned)key >= (unsigned)nkeys) {  // cannot happen unless binning and kernel disagree
                     ++bad;
                     continue;
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                 if ((unsigned)pos < (unsigned)batch) {
                     // meta = slice key | the footprint origin's cell offset in the tile (< 8192: sorted_plan)
                     smo[pos] = make_uint2(((uint32_t)key << 16) | (uint32_t)((rec[q].lxy >> 16) * g.ldw + (rec[q].lxy & 0xffff)),
-                                          (uint32_t)rec[q].orig);
+                                          (uint32_t)(AW ? rec[q].kslice : rec[q].orig));
                     if (!DEGRID) svals[pos] = val[q];
                 } else
                     ++bad;
@@ -265,7 +272,7 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             if (!DEGRID) v = svals[idx];
         };
         auto issue = [&](double2(&k)[NSTEP], int key, int len) {
-            key = min(max(key, 0), nkeys - 1);  // never form an address outside the kernel table
+            key = min(max(key, 0), (AW ? g.nslices : nkeys) - 1);  // never form an address outside the kernel table
             asm volatile("" : "+s"(key));       // (an empty run repeats a key: keep its loads loads, not copies)
             const double2 *kp = gcf + (size_t)(first_slice + key) * S2;
             if (ABL & 4) {
@@ -288,12 +295,12 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
             const double2 vB = vN;
             load_block(b0 + 64, moN, vN);  // the next block's records travel while this one is accumulated
             const int bcnt = min(64, seg_hi - b0);
-            const uint32_t mykey = mo.x >> 16;
+            const uint32_t mykey = AW ? mo.y : mo.x >> 16;
             const uint32_t prevkey = (uint32_t)__shfl_up((int)mykey, 1, 64);
             unsigned long long bits = __ballot(lane < bcnt && (lane == 0 || mykey != prevkey));  // run starts
             double2 kx[EXTRA > 0 ? EXTRA : 1];
             if (EXTRA > 0) {  // this lane's record: the taps its run steps leave out (used after the block's runs)
-                const double2 *kp = gcf + (size_t)(first_slice + min((int)mykey, nkeys - 1)) * S2 + (S2 - EXTRA);
+                const double2 *kp = gcf + (size_t)(first_slice + min((int)mykey, (AW ? g.nslices : nkeys) - 1)) * S2 + (S2 - EXTRA);
 #pragma unroll
                 for (int e = 0; e < EXTRA; ++e) kx[e] = (ABL & 4) ? make_double2(1.0, 2.0) : kp[e];
             }
@@ -309,7 +316,8 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
                 start = (int)__builtin_ctzll(bits);
                 bits &= bits - 1;
                 len = (bits ? (int)__builtin_ctzll(bits) : bcnt) - start;
-                key = lastKey = (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, start) >> 16);
+                key = lastKey = AW ? __builtin_amdgcn_readlane((int)mo.y, start)
+                                   : (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, start) >> 16);
             };
             auto process = [&](const double2(&k)[NSTEP], int start, int len) {
                 if (!DEGRID) {
@@ -564,9 +572,10 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
 {
     // square supports with a compile-time instantiation below
     if (g.gh != g.gw || g.gh < 5 || g.gh > 16) return false;
-    if (g.per_vis || g.T > 128) return false;
+    if (g.T > 128) return false;
     const int planes = (g.W + g.ngroups - 1) / g.ngroups + 1;  // groups differ by at most one plane
-    const int64_t keys = (int64_t)planes * g.Q * g.Q * g.P;
+    // (aw gridders: the sort is by kslice mod 4096)
+    const int64_t keys = g.per_vis ? 4096 : (int64_t)planes * g.Q * g.Q * g.P;
     if (keys >= 65536) return false;
     const size_t plane = (size_t)g.lrows * g.ldw * 8;
     if (plane > (size_t)SORTED_IM_OFF) return false;
@@ -588,6 +597,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     Tables t = tables_of(ctx, g);
     const VisRec *recs = (const VisRec *)ctx->recs.ptr;
     if (g.chunk > batch) return fail(ctx, GRIDHIP_EINVAL, "sorted kernel: chunk %d exceeds its work-item capacity %d", g.chunk, batch);
+    if (g.per_vis && degrid) return fail(ctx, GRIDHIP_EUNSUPPORTED, "no degrid form of the aw tile kernel");
     // persistent work-groups: as many as can be resident (LDS-limited), pulling items from per-group queues
     int per_cu = (int)((size_t)ctx->max_lds / lds_bytes);
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
@@ -610,9 +620,18 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
                            t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
                            t.scalars, svals, smo);                                                               \
     } while (0)
+#define GH_LAUNCH_AW(S_)                                                                                         \
+    do {                                                                                                         \
+        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, false, 0, true>));                                   \
+        hipLaunchKernelGGL((tile_grid_sorted_kernel<S_, false, 0, true>), gr, bl, lds_bytes, ctx->stream, g, recs, \
+                           t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
+                           t.scalars, svals, smo);                                                               \
+    } while (0)
 #define GH_CASE(S_)             \
     case S_:                    \
-        if (degrid)             \
+        if (g.per_vis)          \
+            GH_LAUNCH_AW(S_);   \
+        else if (degrid)        \
             GH_LAUNCH(S_, true); \
         else                    \
             GH_LAUNCH(S_, false); \
@@ -637,6 +656,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     }
 #undef GH_CASE
 #undef GH_LAUNCH
+#undef GH_LAUNCH_AW
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }

@@ -239,6 +239,23 @@ class Context:
 
     convgrid3 = convgrid4
 
+    def aw_stats(self, S=15):
+        """What the last convgrid4 did: visibilities keyed, distinct kernels built, the hit rate of the per-key
+        de-duplication, the fp64 flops of the kernel builds and (timing enabled) their device time."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.gridhip_aw_last_stats(self._h, C.byref(a), C.byref(b)))
+        c = S // 2
+        macs = sum(S - abs(y - c) for y in range(S)) ** 2  # complex products of one 'same' S x S convolution (15: 28 561)
+        out = {"vis_keyed": a.value, "kernels_built": b.value,
+               "hit_rate": 1.0 - b.value / a.value if a.value else 0.0,
+               "conv_flops_per_call": 8.0 * macs * b.value}
+        try:
+            t = self.timing(0)
+            out.update(build_ms=t[1], grid_ms=t[2])
+        except GridHipError:
+            pass
+        return out
+
     def aw_imaging(self, theta, lam, wkernels, wbins, akernels, uvw, src, vis):
         """src/Gridding.hs:452-478 (aw_imagingOld :480-506 gives the same grid); src = (a1, a2, t, f)"""
         u, v, w, st = self._uvw(uvw)

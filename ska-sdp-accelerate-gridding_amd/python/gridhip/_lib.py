@@ -61,6 +61,7 @@ SIGNATURES = {
     "gridhip_w_cache_imaging": (ci, [vp, i64, i64, i64, i64, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp]),
     "gridhip_awgrid": (ci, [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "gridhip_awgrid_dev": (ci, [vp, i64, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "gridhip_aw_last_stats": (ci, [vp, C.POINTER(i64), C.POINTER(i64)]),
     "gridhip_aw_imaging": (ci, [vp, C.c_double, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp,
                                 vp, vp]),
     "gridhip_do_imaging": (ci, [vp, ci, i64, i64, i64, i64, i64, vp, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp,

@@ -76,3 +76,95 @@ def test_aw_imaging(ctx, oracle):
     wb = np.array([oracle.find_closest(wvals, x) for x in w])
     ref = oracle.awgrid(wk, ak, np.zeros((64, 64), dtype=np.complex128), u / lam, v / lam, wb, a1, a2, vis)
     assert rel(got, ref) < TOL
+
+
+def _aw_case(seed, N, W, Q, S, A, nb, dumps, drift=0.02):
+    """baseline-structured stream: nb baselines x `dumps` consecutive samples drifting by `drift` cells each"""
+    rng = np.random.default_rng(seed)
+    wk = rng.normal(size=(W, Q, Q, S, S)) + 1j * rng.normal(size=(W, Q, Q, S, S))
+    ak = rng.normal(size=(A, S, S)) + 1j * rng.normal(size=(A, S, S))
+    u0, v0 = rng.uniform(-0.4, 0.4, nb), rng.uniform(-0.4, 0.4, nb)
+    ang = rng.uniform(0, 2 * np.pi, nb)
+    d = np.arange(dumps)
+    u = (u0[:, None] + d[None, :] * np.cos(ang)[:, None] * drift / N).ravel()
+    v = (v0[:, None] + d[None, :] * np.sin(ang)[:, None] * drift / N).ravel()
+    rep = lambda a: np.repeat(a, dumps)
+    wb, a1, a2 = rep(rng.integers(0, W, nb)), rep(rng.integers(0, A, nb)), rep(rng.integers(0, A, nb))
+    n = nb * dumps
+    vis = rng.normal(size=n) + 1j * rng.normal(size=n)
+    return wk, ak, u, v, wb, a1, a2, vis
+
+
+@pytest.mark.parametrize("S", [15, 7, 9, 12])
+def test_aw_key_cache_on_and_off(ctx, oracle, S):
+    """Per-key de-duplication (option aw_cache): the kernel of every distinct (a1, a2, wbin, yf, xf) is built once and
+    the visibilities that share it reuse it.  Same grid with the cache on and off (where every visibility gets a
+    private kernel, as the reference evaluates), both against the oracle; the stats report the repetition."""
+    N, W, Q, A = 192, 3, 4, 5
+    wk, ak, u, v, wb, a1, a2, vis = _aw_case(40 + S, N, W, Q, S, A, 400, 6)
+    wb[::37] = W      # out of range: dropped and counted, with the cache on and off
+    a1[5::41] = -1
+    keep = (wb < W) & (a1 >= 0)
+    ref = oracle.awgrid(wk, ak, np.zeros((N, N), dtype=np.complex128), u[keep], v[keep], wb[keep], a1[keep], a2[keep],
+                        vis[keep], direct=True)
+    try:
+        ctx.set_option("aw_cache", 1)
+        on = ctx.convgrid4(wk, ak, np.zeros((N, N), dtype=np.complex128), (u, v, None), (wb, a1, a2), vis)
+        st_on, drop_on, err_on = ctx.aw_stats(S), ctx.last_dropped(), ctx.get_option("errors")
+        ctx.set_option("aw_cache", 0)
+        off = ctx.convgrid4(wk, ak, np.zeros((N, N), dtype=np.complex128), (u, v, None), (wb, a1, a2), vis)
+        st_off, drop_off = ctx.aw_stats(S), ctx.last_dropped()
+    finally:
+        ctx.set_option("aw_cache", 1)
+    assert rel(on, ref) < TOL and rel(off, ref) < TOL and err_on == 0
+    assert drop_on == drop_off == int((~keep).sum())
+    assert st_off["kernels_built"] == st_off["vis_keyed"] == len(u)
+    assert st_on["vis_keyed"] == len(u) and st_on["kernels_built"] < 0.6 * int(keep.sum())
+    assert st_on["hit_rate"] > 0.4
+
+
+def test_aw_at_the_configured_grid_size(ctx, oracle):
+    """BASELINE configs[3]'s grid (4096^2, 15x15, 128 planes, 512 antennas): a sample small enough for the oracle is
+    checked through the checksum sum(G) = sum_k vis_k * sum_ij conj(awkern_k)[i, j] (every tap lands inside the grid),
+    and a stream of 5 x 10^6 visibilities (two batches of the kernel table) through linearity in the visibilities."""
+    import torch
+    N, W, Q, S, A = 4096, 128, 8, 15, 512
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # (smooth kernels keep the checksum well conditioned)
+    rng = np.random.default_rng(2)
+    j = np.arange(S) - S // 2
+    base = np.exp(-(j[:, None] ** 2 + j[None, :] ** 2) / 18.0)
+    wk = base[None, None, None] * np.exp(1j * rng.uniform(0, 0.5, size=(W, Q, Q, 1, 1))) * (1 + 0.1 * rng.normal(size=(W, Q, Q, S, S)))
+    ak = base[None] * np.exp(1j * rng.uniform(0, 0.5, size=(A, 1, 1))) * (1 + 0.1 * rng.normal(size=(A, S, S)))
+    nb, dumps = 2500, 8
+    _, _, u, v, wb, a1, a2, vis = _aw_case(11, N, W, Q, S, A, nb, dumps)
+    G = ctx.convgrid4(t(wk), t(ak), torch.zeros((N, N), dtype=torch.complex128, device=dev), (t(u), t(v), None),
+                      (t(wb), t(a1), t(a2)), t(vis))
+    st = ctx.aw_stats(S)
+    total = complex(G.sum().item())
+    # the oracle's kernels, one per DISTINCT key of the sample
+    keys = {}
+    expect = 0j
+    _, xfs = oracle.frac_coord(N, Q, u)
+    _, yfs = oracle.frac_coord(N, Q, v)
+    for k in range(len(u)):
+        key = (int(a1[k]), int(a2[k]), int(wb[k]), int(yfs[k]), int(xfs[k]))
+        if key not in keys:
+            keys[key] = np.conj(oracle.aw_kernel_fn2(key[3], key[4], wk[key[2]], ak[key[0]], ak[key[1]], direct=True)).sum()
+        expect += vis[k] * keys[key]
+    assert abs(total - expect) / abs(expect) < 1e-9
+    assert st["kernels_built"] == len(keys) and ctx.get_option("errors") == 0 and ctx.last_dropped() == 0
+    # linearity at 5 x 10^6 visibilities (> one batch of the kernel table)
+    nb = 625_000
+    _, _, u, v, wb, a1, a2, vis = _aw_case(12, N, W, Q, S, A, nb, dumps)
+    v2 = np.random.default_rng(5).normal(size=len(u)) + 1j * np.random.default_rng(6).normal(size=len(u))
+    tu, tv, twb, ta1, ta2, twk, tak = t(u), t(v), t(wb), t(a1), t(a2), t(wk), t(ak)
+    z = lambda: torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    Ga = ctx.convgrid4(twk, tak, z(), (tu, tv, None), (twb, ta1, ta2), t(vis))
+    st = ctx.aw_stats(S)
+    Gb = ctx.convgrid4(twk, tak, z(), (tu, tv, None), (twb, ta1, ta2), t(v2))
+    Gc = ctx.convgrid4(twk, tak, z(), (tu, tv, None), (twb, ta1, ta2), t(2.0 * vis - 0.5j * v2))
+    lin = (Gc - (2.0 * Ga - 0.5j * Gb)).abs().max().item() / Gc.abs().max().item()
+    assert lin < 1e-11 and ctx.get_option("errors") == 0
+    assert st["vis_keyed"] == len(u) and 0.3 < st["hit_rate"] < 0.95
