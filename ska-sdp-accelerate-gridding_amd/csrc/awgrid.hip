@@ -128,6 +128,7 @@ __global__ void aw_keys_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int3
                 id = -(int32_t)h - 16;  // resolved by aw_kid_kernel once every number has been handed out
             }
         }
+        if (bad && !cache) ukey[k] = 0;  // (every table entry is built: give the dropped one's a key that exists)
         kid[k] = id;
         ok[k] = bad ? -1 : 0;
     }
@@ -176,9 +177,12 @@ __global__ void aw_build_generic_kernel(int S, const double2 *__restrict__ wkern
 // whose output row y = r + i - c exists, four FMAs each, from registers: 30 reads per 169 complex products at
 // 15 x 15.  b comes from an LDS copy of the w-kernel slice whose rows are followed by c zeros (row pitch S + c, c
 // zeros in front of row 0), so a column index of -c .. S-1+c needs no bounds logic.
-template <int S>
+// PAIR: the same machine builds the antenna-pair products: entry s = convolve2d(akerns[p], akerns[q]) for
+// pairlist[s] = p * A + q (wkerns = pairk = akerns, not conjugated).
+template <int S, bool PAIR>
 __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
                                                        const unsigned long long *__restrict__ ukey,
+                                                       const int32_t *__restrict__ pairlist, int64_t A,
                                                        const int32_t *__restrict__ counters, int which, int32_t fixed_count,
                                                        int32_t cap, double2 *__restrict__ table)
 {
@@ -199,9 +203,20 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
     for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
         const int64_t id = grp * 4 + q;
         const bool have = id < nk;
-        const unsigned long long key = have ? ukey[id] : 0ull;
-        const double2 *pk = pairk + (have ? (size_t)(key >> 30) * S2 : 0);
-        const double2 *wk = wkerns + (have ? (size_t)(key & 0x3fffffffull) * S2 : 0);
+        size_t ia = 0, ib = 0;  // which S x S arrays are convolved
+        if (have) {
+            if (PAIR) {
+                const int64_t pq = pairlist[id];
+                ia = (size_t)(pq / A);
+                ib = (size_t)(pq - (int64_t)ia * A);
+            } else {
+                const unsigned long long key = ukey[id];
+                ia = (size_t)(key >> 30);
+                ib = (size_t)(key & 0x3fffffffull);
+            }
+        }
+        const double2 *pk = pairk + ia * S2;
+        const double2 *wk = wkerns + ib * S2;
         __builtin_amdgcn_wave_barrier();  // (the previous group's reads of this LDS region are done: same wave)
         {   // all of the lane's loads first, then its LDS stores (a load-store loop would pay the memory latency per trip)
             constexpr int NE = (S2 + 15) / 16;
@@ -251,7 +266,7 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
         if (have && x < S) {  // out[x * S + y]: the result comes out transposed, and is conjugated
             double2 *out = table + (size_t)id * S2 + (size_t)x * S;
 #pragma unroll
-            for (int y = 0; y < S; ++y) out[y] = make_double2(acc[y].x, -acc[y].y);
+            for (int y = 0; y < S; ++y) out[y] = make_double2(acc[y].x, PAIR ? acc[y].y : -acc[y].y);
         }
     }
 }
@@ -281,16 +296,17 @@ __global__ void aw_finish_kernel(int32_t *__restrict__ scalars) { scalars[0] = s
 using namespace gridhip;
 
 namespace {
-template <int S>
+template <int S, bool PAIR>
 int launch_build(gridhip_ctx *ctx, const double2 *wk, const double2 *pairk, const unsigned long long *ukey,
-                 const int32_t *counters, int which, int32_t fixed, int32_t cap, double2 *table)
+                 const int32_t *pairlist, int64_t A, const int32_t *counters, int which, int32_t fixed, int32_t cap,
+                 double2 *table)
 {
     constexpr int C = S / 2, PB = S + C, BSZ = C + S * PB;
     const size_t lds = (size_t)16 * (S * S + BSZ) * sizeof(double2);
-    GH_CHECK(raise_lds(ctx, aw_build_kernel<S>));
-    // one work-group (four waves, one per SIMD) per CU; the loop strides over the keys
-    hipLaunchKernelGGL(aw_build_kernel<S>, dim3(ctx->num_cu), dim3(256), lds, ctx->stream, wk, pairk, ukey, counters, which,
-                       fixed, cap, table);
+    GH_CHECK(raise_lds(ctx, aw_build_kernel<S, PAIR>));
+    // one work-group (four waves, one per SIMD) per CU; the loop strides over the entries
+    hipLaunchKernelGGL((aw_build_kernel<S, PAIR>), dim3(ctx->num_cu), dim3(256), lds, ctx->stream, wk, pairk, ukey, pairlist, A,
+                       counters, which, fixed, cap, table);
     return GRIDHIP_OK;
 }
 }  // namespace
@@ -367,10 +383,16 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
     if (blocks > ctx->num_cu * 8) blocks = ctx->num_cu * 8;
     hipLaunchKernelGGL(aw_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n, A, a1, a2, slot, pairlist,
                        counters, pair_cap);
-    {
-        int pb = pair_cap < ctx->num_cu * 8 ? pair_cap : ctx->num_cu * 8;
-        hipLaunchKernelGGL(aw_pair_kernel, dim3((unsigned)(pb > 0 ? pb : 1)), dim3(256), 2 * S2 * sizeof(double2), ctx->stream,
-                           A, (int)S, (const double2 *)akerns, pairlist, counters, pair_cap, pairk);
+    switch (S) {
+#define AW_CASE(S_) \
+    case S_: GH_CHECK((launch_build<S_, true>(ctx, (const double2 *)akerns, (const double2 *)akerns, nullptr, pairlist, A, counters, 0, 0, pair_cap, pairk))); break;
+        AW_CASE(5) AW_CASE(7) AW_CASE(9) AW_CASE(11) AW_CASE(13) AW_CASE(15)
+#undef AW_CASE
+        default: {
+            int pb = pair_cap < ctx->num_cu * 8 ? pair_cap : ctx->num_cu * 8;
+            hipLaunchKernelGGL(aw_pair_kernel, dim3((unsigned)(pb > 0 ? pb : 1)), dim3(256), 2 * S2 * sizeof(double2), ctx->stream,
+                               A, (int)S, (const double2 *)akerns, pairlist, counters, pair_cap, pairk);
+        }
     }
     GH_CHECK_HIP(ctx, hipGetLastError());
 
@@ -392,7 +414,7 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         const int which = cache ? 1 : -1;
         switch (S) {
 #define AW_CASE(S_) \
-    case S_: GH_CHECK(launch_build<S_>(ctx, (const double2 *)wkerns, pairk, ukey, counters, which, (int32_t)m, (int32_t)batch, table)); break;
+    case S_: GH_CHECK((launch_build<S_, false>(ctx, (const double2 *)wkerns, pairk, ukey, nullptr, A, counters, which, (int32_t)m, (int32_t)batch, table))); break;
             AW_CASE(5) AW_CASE(7) AW_CASE(9) AW_CASE(11) AW_CASE(13) AW_CASE(15)
 #undef AW_CASE
             default: {
