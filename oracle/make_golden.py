@@ -5,6 +5,12 @@ Provenance of each fixture:
 
   brokennumbers.npz   RECORDED by the reference: inputs are the literals of old/BrokenNumbers.hs:47-48
                       (`vcomplex`), expected grid is the interpreter output printed at :86-91.
+  brokennumbers_real.npz  RECORDED by the reference: the real-valued twin of the above (`vdouble`, old/BrokenNumbers.hs:50-51),
+                      expected grid is the output printed at :101-106 (`test2`, interpreter and CPU backend agree).
+  fixbounds.npz       DERIVED: inputs are the literals of test/GridTesting.hs:365-387 (`testFixbounds`: the ten points
+                      scattered four times, with offsets (0,0), (1,1), (1,0), (0,1), through fixoutofboundsOLD :428-439);
+                      expected grid evaluated here from that definition with plain Python loops.  It is convgrid with a
+                      2 x 2 kernel of ones.
   fixbounds2.npz      DERIVED: inputs are the literals of test/GridTesting.hs:389-426 (`testFixbounds2`),
                       expected grid evaluated here from that test's own definition with plain Python loops.
   smalltest_aw.npz    DERIVED: inputs are the literals of test/SmallTest.hs:51-76; expected grid from the
@@ -40,6 +46,38 @@ def brokennumbers():
     expected[3, 3] = 46 + 4j
     expected[4, 2] = 34 + 4j
     np.savez(os.path.join(OUT, "brokennumbers.npz"), x=xs, y=ys, val=val, passes=np.int64(2), expected=expected)
+
+
+def brokennumbers_real():
+    xs = np.array([(2 * x) % 5 for x in range(10)], dtype=np.int64)
+    ys = np.array([(3 * x + 1) % 5 for x in range(10)], dtype=np.int64)
+    val = np.array([float(x + 5) for x in range(10)])
+    expected = np.zeros((5, 5), dtype=np.float64)
+    # old/BrokenNumbers.hs:101-106 (`test2`), rows top to bottom
+    expected[0, 1] = 42.0
+    expected[1, 0] = 30.0
+    expected[2, 4] = 38.0
+    expected[3, 3] = 46.0
+    expected[4, 2] = 34.0
+    np.savez(os.path.join(OUT, "brokennumbers_real.npz"), x=xs, y=ys, val=val, passes=np.int64(2), expected=expected)
+
+
+def fixbounds():
+    x = np.array([(2 * k) % 5 for k in range(10)], dtype=np.int64)
+    y = np.array([(3 * k + 1) % 5 for k in range(10)], dtype=np.int64)
+    vis = np.array([complex(k + 5, 1.0) for k in range(10)])
+    G = np.zeros((5, 5), dtype=np.complex128)
+    for offy, offx in ((0, 0), (1, 1), (1, 0), (0, 1)):      # fullrepli i j: offsety = i, offsetx = j (:373-386)
+        for k in range(10):
+            idx, idy = x[k] + offx, y[k] + offy
+            if idx < 0 or idy < 0 or idx >= 5 or idy >= 5:
+                continue  # fixoutofboundsOLD: (-offx, -offy, 0) -> adds 0 to G[0, 0]
+            G[idy, idx] += vis[k]
+    # the same through convgrid: a [1,1,2,2] kernel of ones, coordinates whose footprint origin (cell - gw/2) is (x, y)
+    pu = (x + 1 - 2) / 5.0
+    pv = (y + 1 - 2) / 5.0
+    np.savez(os.path.join(OUT, "fixbounds.npz"), x=x, y=y, vis=vis, gcf=np.ones((1, 1, 2, 2), dtype=np.complex128),
+             pu=pu, pv=pv, expected=G)
 
 
 def fixbounds2():
@@ -108,6 +146,8 @@ def wkernels():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     brokennumbers()
+    brokennumbers_real()
+    fixbounds()
     fixbounds2()
     smalltest_aw()
     convgrid2_small()

@@ -267,6 +267,14 @@ def test_golden_fixtures(ctx, golden):
     for _ in range(int(g["passes"])):
         ctx.grid(G, ((g["x"] - 2) / 5.0, (g["y"] - 2) / 5.0, None), g["val"])
     assert np.array_equal(G, g["expected"])
+    g = golden("brokennumbers_real")  # ... and its real-valued twin (old/BrokenNumbers.hs:101-106)
+    G = np.zeros((5, 5), dtype=np.complex128)
+    for _ in range(int(g["passes"])):
+        ctx.grid(G, ((g["x"] - 2) / 5.0, (g["y"] - 2) / 5.0, None), g["val"].astype(np.complex128))
+    assert np.array_equal(G.real, g["expected"]) and not G.imag.any()
+    g = golden("fixbounds")  # test/GridTesting.hs:365-387: the four offsets of a 2x2 footprint of ones
+    G = ctx.convgrid(g["gcf"], np.zeros((5, 5), dtype=np.complex128), (g["pu"], g["pv"], None), g["vis"])
+    assert np.array_equal(G, g["expected"])
     g = golden("fixbounds2")
     G = ctx.convgrid(g["gcf"], np.zeros((5, 5), dtype=np.complex128), (g["pu"], g["pv"], None), g["vis"])
     assert np.array_equal(G, g["expected"])

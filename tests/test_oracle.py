@@ -33,7 +33,30 @@ def test_kat_brokennumbers_recorded(oracle, golden):
         assert np.array_equal(G, g["expected"])
 
 
+def test_kat_brokennumbers_real_recorded(oracle, golden):
+    """the real-valued twin the reference records too (old/BrokenNumbers.hs:101-106; interpreter and CPU backend agree)"""
+    g = golden("brokennumbers_real")
+    for impl in (oracle, P):
+        G = np.zeros((5, 5), dtype=np.complex128)
+        for _ in range(int(g["passes"])):
+            impl.grid(G, (g["x"] - 2) / 5.0, (g["y"] - 2) / 5.0, g["val"].astype(np.complex128))
+        assert np.array_equal(G.real, g["expected"]) and not G.imag.any()
+
+
 # ---- derived KATs (reference-literal inputs) -------------------------------------------------
+def test_kat_fixbounds_derived(oracle, golden):
+    """testFixbounds (test/GridTesting.hs:365-387): ten points scattered with the four offsets of a 2x2 footprint,
+    out-of-range ones dropped by fixoutofboundsOLD - convgrid with a 2x2 kernel of ones."""
+    g = golden("fixbounds")
+    for impl in (oracle, P):
+        x, xf = impl.frac_coord(5, 1, g["pu"])
+        y, yf = impl.frac_coord(5, 1, g["pv"])
+        assert np.array_equal(x - 1, g["x"]) and np.array_equal(y - 1, g["y"]) and not xf.any() and not yf.any()
+        G = np.zeros((5, 5), dtype=np.complex128)
+        impl.convgrid(g["gcf"], G, g["pu"], g["pv"], g["vis"])
+        assert np.array_equal(G, g["expected"])  # small integers: exact
+
+
 def test_kat_fixbounds2_derived(oracle, golden):
     g = golden("fixbounds2")
     for impl in (oracle, P):
