@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measure the secondary configurations on one GPU (the headline number comes from bench.py):
-cfg2 grid, cfg3 grid with the 'core' distribution, cfg3 degrid, cfg4 aw-gridding.  Prints one
-JSON line per measurement; timings are HIP-event totals (pre-pass + kernel) or wall time."""
+cfg2 grid, cfg3 grid with the 'core' distribution, cfg3 degrid, plans, cfg4 aw-gridding with and without the per-key
+cache, the cfg5 share, a support sweep, do_imaging at N = 2400, the host-pointer ABI.  Prints one JSON line per measurement; timings are HIP-event totals (pre-pass + kernel) or wall time."""
 import json
 import os
 import sys
@@ -47,7 +47,7 @@ def report(name, n, t_ms, extra=None):
     print(json.dumps(d), flush=True)
 
 
-which = sys.argv[1:] or ["cfg2", "core", "degrid", "aw"]
+which = sys.argv[1:] or ["cfg2", "core", "degrid", "aw", "cfg5", "plan", "supports", "imaging", "host"]
 if "host" in which:
     # PCIe-inclusive rate of the drop-in host-pointer ABI (pageable numpy arrays in, grid out)
     n, N, W, Q, S = 20_000_000, 4096, 128, 8, 15
@@ -99,18 +99,61 @@ if "core" in which or "degrid" in which:
         del u, v, wb, vis, out
     del gcf, G
 if "aw" in which:
-    # config 4: aw-projection, 4096^2, 15x15, 128 planes, 512 antennas, per-antenna kernel lookup
+    # config 4: aw-projection, 4096^2, 15x15, 128 planes, 512 antennas, per-antenna kernel lookup; baseline-structured
+    # stream (bench.synth_aw_stream), with and without the per-key kernel cache
     N, W, Q, S, A = 4096, 128, 8, 15, 512
     gcf = bench.synth_kernels(W, Q, S, dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(4)
-    ak = torch.complex(torch.randn((A, S, S), generator=gen, device=dev, dtype=torch.float64),
-                       torch.randn((A, S, S), generator=gen, device=dev, dtype=torch.float64)) * 0.05
+    ak = bench.synth_akernels(A, S, dev)
     for n in (1_000_000, 10_000_000):
-        u, v, wb, vis = bench.synth_vis(n, N, W, S, 5, dev)
-        a1 = torch.randint(0, A, (n,), generator=gen, device=dev, dtype=torch.int64)
-        a2 = torch.randint(0, A, (n,), generator=gen, device=dev, dtype=torch.int64)
+        u, v, wb, a1, a2, vis = bench.synth_aw_stream(n, N, W, S, A, 5, dev)
         G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
-        t = wall(lambda: ctx.convgrid4(gcf, ak, G, (u, v, None), (wb, a1, a2), vis), 2)
-        report(f"cfg4 aw-gridding (convgrid4), {A} antennas, no per-key kernel cache", n, t)
-        del u, v, wb, vis, a1, a2, G
+        for cache in (1, 0):
+            ctx.set_option("aw_cache", cache)
+            t = wall(lambda: ctx.convgrid4(gcf, ak, G, (u, v, None), (wb, a1, a2), vis), 3)
+            st = ctx.aw_stats(S)
+            report(f"cfg4 aw-gridding (convgrid4), {A} antennas, per-key kernel cache {'on' if cache else 'off'}", n, t,
+                   {"kernels_built": st["kernels_built"], "hit_rate": round(st["hit_rate"], 4),
+                    "build_ms": round(st.get("build_ms", 0.0), 3), "grid_ms": round(st.get("grid_ms", 0.0), 3)})
+        ctx.set_option("aw_cache", 1)
+        del u, v, wb, a1, a2, vis, G
+if "cfg5" in which:
+    n, N, W, Q, S = bench.WORKLOADS["cfg5"]
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    u, v, wb, vis = bench.synth_vis(n, N, W, S, 7, dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    t = timed(lambda: ctx.convgrid2(gcf, G, (u, v, None), wb, vis), 3)
+    report("cfg5 share of one GPU: 1.25e8 vis, 8192^2, 15x15, 128 planes", n, t[0],
+           {"prepass_ms": round(float(t[1]), 3), "kernel_ms": round(float(t[2]), 3)})
+    del gcf, u, v, wb, vis, G
+if "supports" in which:
+    # cfg3's shape with other supports (2e7 visibilities): squares through the tap-reusing kernel directly (5..16) or
+    # cut into square parts (above 16), and a non-square one
+    n, N, W, Q = 20_000_000, 4096, 128, 8
+    u, v, wb, vis = bench.synth_vis(n, N, W, 31, 8, dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    for gh, gw in ((5, 5), (7, 7), (9, 9), (11, 11), (13, 13), (15, 15), (16, 16), (17, 17), (21, 21), (25, 25), (31, 31), (9, 5)):
+        gcf = bench.synth_kernels(W, Q, max(gh, gw), dev)[..., :gh, :gw].contiguous()
+        t = timed(lambda: ctx.convgrid2(gcf, G, (u, v, None), wb, vis), 3)
+        report(f"support {gh}x{gw}", n, t[0], {"prepass_ms": round(float(t[1]), 3), "kernel_ms": round(float(t[2]), 3),
+                                               "Gtaps_per_s_kernel": round(n * gh * gw / float(t[2]) / 1e6, 1)})
+        del gcf
+    del u, v, wb, vis, G
+if "imaging" in which:
+    # do_imaging (src/Gridding.hs:509-549) end to end at the driver's size, N = theta * lam = 2400
+    # (src/ImageDataset.hs:32-33): mirror, weights, two gridding passes (image, PSF), Hermitian fill, two 2400^2
+    # non-power-of-two hipFFTs, normalisation.  Host arrays in, images out (PCIe included).
+    theta, lam = 0.008, 300000
+    rng = np.random.default_rng(3)
+    for n in (1_000_000, 10_000_000):
+        uvw = np.stack([rng.uniform(-0.45 * lam, 0.45 * lam, n), rng.uniform(-0.45 * lam, 0.45 * lam, n),
+                        rng.uniform(0, 20000, n)], axis=1)
+        vis = rng.normal(size=n) + 1j * rng.normal(size=n)
+        z = np.zeros(n, dtype=np.int64)
+        for name, imgfn in (("simple_imaging", ("simple",)),
+                            ("w_cache_imaging (wstep 2000, qpx 4, npixFF 256, 15x15)", ("w_cache", dict(wstep=2000, qpx=4, npixFF=256, npixKern=15)))):
+            ctx.do_imaging(theta, lam, uvw, z, z, z, z, vis, imgfn)
+            t0 = time.perf_counter()
+            img, psf, pmax = ctx.do_imaging(theta, lam, uvw, z, z, z, z, vis, imgfn)
+            dt = (time.perf_counter() - t0) * 1e3
+            report(f"do_imaging N=2400, {name}, host arrays in / images out", n, dt, {"pmax": float(pmax)})
+        del uvw, vis

@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC has 4 slots, MI355X_MICROARCH.md).
 # usage: tools/profile.sh <tag> [bench args...]      outputs under gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
