@@ -393,9 +393,11 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
 
 // ---- two-level scatter ----------------------------------------------------------------------
 // In-place exclusive scan of hist[0..nent), nent <= 1024, by NT threads (consecutive entries per thread);
-// reserve(e, count, base) is called for every non-empty entry; wtot[16] receives the total.
+// reserve(e, count, base) is called for every non-empty entry and its result kept in res[] (one slot per entry of
+// the thread) - the caller publishes the results later, so that a returning global atomic issued in `reserve` is not
+// waited for here; wtot[16] receives the total.
 template <int NT, typename F>
-__device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *wtot, F &&reserve)
+__device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *wtot, int (&res)[1024 / NT], F &&reserve)
 {
     constexpr int EPT = 1024 / NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -419,13 +421,25 @@ __device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *w
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const int e = tid * EPT + k;
+        res[k] = 0;
         if (e < nent) {
             hist[e] = base;
-            if (c[k]) reserve(e, c[k], base);
+            if (c[k]) res[k] = reserve(e, c[k], base);
         }
         base += c[k];
     }
     if (tid == NT - 1) wtot[16] = base;
+}
+// the second half: gbase[e] = res (after the work that did not need it)
+template <int NT>
+__device__ __forceinline__ void publish_entries(int32_t *gbase, int nent, const int (&res)[1024 / NT])
+{
+    constexpr int EPT = 1024 / NT;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = threadIdx.x * EPT + k;
+        if (e < nent) gbase[e] = res[k];
+    }
 }
 
 // Level 1.  tmp is laid out like the final record array at coarse granularity: coarse bin c owns
@@ -488,9 +502,11 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
         for (int q = 0; q < PER; ++q)
             rank[q] = b[q].bin >= 0 ? atomicAdd(&hist[b[q].bin >> shift], 1) : 0;
         __syncthreads();
-        // exclusive scan of the counts and the global reservations
-        scan_entries<NT>(hist, ncoarse, wtot, [&](int e, int c, int base) {
-            gbase[e] = bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
+        // exclusive scan of the counts and the global reservations; the returning atomics travel while the chunk
+        // is sorted in LDS (which needs the local offsets only)
+        int res[1024 / NT];
+        scan_entries<NT>(hist, ncoarse, wtot, res, [&](int e, int c, int base) {
+            return bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
         });
         __syncthreads();
 #pragma unroll
@@ -503,6 +519,7 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
             r.set(b[q].lxy, b[q].kslice, (int32_t)kv, b[q].bin);
             sorted[hist[b[q].bin >> shift] + rank[q]] = r;
         }
+        publish_entries<NT>(gbase, ncoarse, res);
         __syncthreads();
         const int total = wtot[16];
         for (int i = tid; i < total; i += NT) {
@@ -552,7 +569,15 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
     }
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         const int64_t c1 = min(c0 + CHUNK, hi);
-        int b_first = tmp[c0].bin(), b_last = tmp[c1 - 1].bin();
+        // the chunk's first and last record are in two threads' prefetch registers: hand them round through LDS
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t i = c0 + q * NT + tid;
+            if (i == c0) wtot[24] = nxt[q].bin();
+            if (i == c1 - 1) wtot[25] = nxt[q].bin();
+        }
+        __syncthreads();
+        int b_first = wtot[24], b_last = wtot[25];
         b_first = min(max(b_first, 0), g.nbins - 1);
         b_last = min(max(b_last, b_first), g.nbins - 1);
         const int k0 = (b_first >> shift) << shift, span = (((b_last >> shift) + 1) << shift) - k0;  // bins k0 .. k0 + span
@@ -597,13 +622,15 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
 #pragma unroll
         for (int q = 0; q < PER; ++q) rank[q] = key[q] >= 0 ? atomicAdd(&hist[key[q]], 1) : 0;
         __syncthreads();
-        scan_entries<NT>(hist, span, wtot, [&](int e, int c, int base) {
-            gbase[e] = bin_start[k0 + e] + atomicAdd(&cursor[k0 + e], c) - base;
+        int res[1024 / NT];
+        scan_entries<NT>(hist, span, wtot, res, [&](int e, int c, int base) {
+            return bin_start[k0 + e] + atomicAdd(&cursor[k0 + e], c) - base;
         });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; ++q)
             if (key[q] >= 0) sorted[hist[key[q]] + rank[q]] = r[q];
+        publish_entries<NT>(gbase, span, res);
         __syncthreads();
         const int total = wtot[16];
         for (int i = tid; i < total; i += NT) {

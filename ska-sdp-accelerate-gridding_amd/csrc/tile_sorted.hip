@@ -53,7 +53,7 @@ struct SortedItem {
 // residue) and the sorted list carries the kslice itself in place of `orig`, which gridding does not need; a run
 // is a stretch of equal kslice.
 template <int S, bool DEGRID, int ABL = 0, bool AW = false>
-__global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
+__global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
                                                                 const int32_t *__restrict__ work_start,
                                                                 const double2 *__restrict__ gcf,
@@ -492,6 +492,11 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
         }
     };
 
+    // flush loop: element e = 2 * cell + component; thread t starts at cell t / 2 and moves nthr / 2 cells per trip
+    // (nthr is even)
+    const int fl_r0 = (tid >> 1) / g.lcols, fl_c0 = (tid >> 1) - fl_r0 * g.lcols;
+    const int fl_dr = (nthr >> 1) / g.lcols, fl_dc = (nthr >> 1) - fl_dr * g.lcols;
+
     // ---- pipeline: item i is accumulated while item i+1 is fetched and sorted ---------------------------
     if (is_sorter) prepare(0);
     if (!DEGRID) {
@@ -538,16 +543,24 @@ __global__ void __launch_bounds__(1024, 5) tile_grid_sorted_kernel(Geom g, const
         // Consecutive lanes take (re, im) of consecutive cells, so one atomic instruction covers a
         // contiguous 512-byte run of the interleaved grid row (memory-side fp64 atomics run at full rate
         // on contiguous runs and at half of it on the stride-16 pattern of one component at a time).
-        for (int e = tid; e < 2 * ncell; e += nthr) {
-            const int c = e >> 1, comp = e & 1;
-            const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;
-            const int64_t gx = ox + c_, gy = oy + r_;
-            double *cell = (comp ? lim : lre) + r_ * g.ldw + c_;
-            const double val = *cell;
-            if (val == 0.0) continue;
-            *cell = 0.0;
-            if ((ABL & 2) || gx < 0 || gy < 0 || gx >= g.Wd || gy >= g.H) continue;
-            unsafeAtomicAdd(grid + 2 * (gy * g.Wd + gx) + comp, val);
+        {   // (row, column) of element e advance by constants from trip to trip: no division in the loop
+            const int comp = tid & 1;
+            int r_ = fl_r0, c_ = fl_c0;
+            for (int e = tid; e < 2 * ncell; e += nthr) {
+                const int64_t gx = ox + c_, gy = oy + r_;
+                double *cell = (comp ? lim : lre) + r_ * g.ldw + c_;
+                c_ += fl_dc;
+                r_ += fl_dr;
+                if (c_ >= g.lcols) {
+                    c_ -= g.lcols;
+                    ++r_;
+                }
+                const double val = *cell;
+                if (val == 0.0) continue;
+                *cell = 0.0;
+                if ((ABL & 2) || gx < 0 || gy < 0 || gx >= g.Wd || gy >= g.H) continue;
+                unsafeAtomicAdd(grid + 2 * (gy * g.Wd + gx) + comp, val);
+            }
         }
         __syncthreads();
         if ((ABL & 16) && wave == 0) GH_STAMP(6)  // flush

@@ -126,9 +126,10 @@ if "cfg5" in which:
            {"prepass_ms": round(float(t[1]), 3), "kernel_ms": round(float(t[2]), 3)})
     del gcf, u, v, wb, vis, G
 if "supports" in which:
-    # cfg3's shape with other supports (2e7 visibilities): squares through the tap-reusing kernel directly (5..16) or
-    # cut into square parts (above 16), and a non-square one
-    n, N, W, Q = 20_000_000, 4096, 128, 8
+    # cfg3's shape with other supports: squares through the tap-reusing kernel directly (5..16) or cut into square
+    # parts (above 16), and a non-square one.  GRIDHIP_SWEEP_N sets the stream length (default 2e7; 1e8 = cfg3's own,
+    # where a 31x31 item holds as many visibilities per distinct slice as the 15x15 headline case)
+    n, N, W, Q = int(float(os.environ.get("GRIDHIP_SWEEP_N", "2e7"))), 4096, 128, 8
     u, v, wb, vis = bench.synth_vis(n, N, W, 31, 8, dev)
     G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
     for gh, gw in ((5, 5), (7, 7), (9, 9), (11, 11), (13, 13), (15, 15), (16, 16), (17, 17), (21, 21), (25, 25), (31, 31), (9, 5)):
