@@ -18,8 +18,8 @@ def make_case(seed):
     H = int(rng.integers(17, 400))
     Wd = H if rng.random() < 0.5 else int(rng.integers(17, 400))
     square = rng.random() < 0.7
-    gh = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 11, 13, 15, 17, 21]))
-    gw = gh if square else int(rng.choice([1, 3, 4, 5, 7, 9, 12, 15, 19]))
+    gh = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 11, 13, 15, 17, 21, 25, 31, 33]))
+    gw = gh if square else int(rng.choice([1, 3, 4, 5, 7, 9, 12, 15, 19, 28]))
     Q = int(rng.choice([1, 2, 3, 4, 8]))
     W = int(rng.choice([1, 2, 5, 8, 13, 32]))
     n = int(rng.choice([1, 7, 300, 5000, 40000, 120000]))
@@ -38,11 +38,11 @@ def make_case(seed):
     if rng.random() < 0.6:
         opts["block"] = int(rng.choice([64, 128, 256, 512, 1024]))
     if rng.random() < 0.5:
-        opts["wgroups"] = int(rng.choice([1, 2, 3, 8]))
+        opts["wgroups"] = int(rng.choice([1, 2, 3, 8, 16]))
     if rng.random() < 0.5:
         opts["chunk"] = int(rng.choice([64, 100, 1000, 5000]))
     opts["sort"] = int(rng.choice([0, 1, 2]))
-    opts["prepass"] = int(rng.choice([0, 1, 2]))  # one- or two-level scatter in the binning pre-pass
+    opts["prepass"] = int(rng.choice([0, 1, 2, 4, 5]))  # one- or two-level scatter in the binning pre-pass (and its variants)
     return (H, Wd, gcf, u, v, wb, vis, opts)
 
 
@@ -72,3 +72,44 @@ def test_fuzz_convgrid2_and_degrid2(ctx, oracle, seed):
     assert rel(got, ref) < TOL, (H, Wd, gcf.shape, len(u), opts)
     if np.abs(dref).max() > 0:
         assert rel(dgot, dref) < TOL, (H, Wd, gcf.shape, len(u), opts)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_awgrid(ctx, oracle, seed):
+    """aw gridders: random supports (compile-time and generic build kernels, tap-reusing and general tile kernels),
+    antenna / plane / oversampling counts, repeated and unique keys, the per-key cache on and off, bad indices."""
+    rng = np.random.default_rng(7000 + seed)
+    S = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 8, 12, 16, 19]))
+    N = int(rng.integers(2 * S + 4, 260))
+    W, Q, A = int(rng.choice([1, 2, 5])), int(rng.choice([1, 2, 4])), int(rng.choice([2, 3, 9]))
+    nb = int(rng.choice([1, 5, 60, 400]))
+    dumps = int(rng.choice([1, 3, 8]))
+    n = nb * dumps
+    wk = rng.normal(size=(W, Q, Q, S, S)) + 1j * rng.normal(size=(W, Q, Q, S, S))
+    ak = rng.normal(size=(A, S, S)) + 1j * rng.normal(size=(A, S, S))
+    u0, v0 = rng.uniform(-0.55, 0.55, nb), rng.uniform(-0.55, 0.55, nb)
+    drift = float(rng.choice([0.0, 0.02, 0.3])) / N
+    d = np.arange(dumps)
+    u = (u0[:, None] + d[None, :] * drift).ravel()
+    v = (v0[:, None] - d[None, :] * drift).ravel()
+    rep = lambda a: np.repeat(a, dumps)
+    wb, a1, a2 = rep(rng.integers(0, W, nb)), rep(rng.integers(0, A, nb)), rep(rng.integers(0, A, nb))
+    vis = rng.normal(size=n) + 1j * rng.normal(size=n)
+    if n > 4:
+        wb[1], a2[3] = W + 2, -5
+    keep = (wb >= 0) & (wb < W) & (a2 >= 0)
+    start = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    ref = oracle.awgrid(wk, ak, start.copy(), u[keep], v[keep], wb[keep], a1[keep], a2[keep], vis[keep], direct=True)
+    cache = int(rng.integers(0, 2))
+    sort = int(rng.choice([0, 2]))
+    try:
+        ctx.set_option("aw_cache", cache)
+        ctx.set_option("sort", sort)
+        got = ctx.convgrid4(wk, ak, start.copy(), (u, v, None), (wb, a1, a2), vis)
+        st = ctx.aw_stats(S)
+    finally:
+        ctx.set_option("aw_cache", 1)
+        ctx.set_option("sort", 0)
+    assert ctx.get_option("errors") == 0
+    assert rel(got, ref) < TOL, (S, N, W, Q, A, nb, dumps, cache, sort)
+    assert st["vis_keyed"] == n and (st["kernels_built"] == n if not cache else st["kernels_built"] <= max(int(keep.sum()), 1))
