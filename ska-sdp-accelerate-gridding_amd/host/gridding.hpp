@@ -226,4 +226,34 @@ class Backend {  // plays the role of the (run, runN) pair of `Runners`, src/Gri
     gridhip_ctx *ctx_ = nullptr;
 };
 
+
+// A whole node: visibility-sharded gridding over several GPUs of one process with one RCCL fp64 all-reduce of the
+// partial grids (include/gridhip.h, gridhip_comm_*).  The reference has no counterpart (app/Main.hs:46-53 picks one
+// (run, runN) pair); the signature stays convgrid2's.
+class Node {
+   public:
+    explicit Node(int ndev, const int *dev_ids = nullptr)
+    {
+        int rc = gridhip_comm_create(ndev, dev_ids, &comm_);
+        if (rc) throw Error(rc, std::string("gridhip_comm_create: ") + gridhip_comm_last_error(nullptr));
+    }
+    ~Node() { gridhip_comm_destroy(comm_); }
+    Node(const Node &) = delete;
+    Node &operator=(const Node &) = delete;
+    int devices() const { return gridhip_comm_ndev(comm_); }
+
+    Matrix<Visibility> convgrid2(const WKernels &gcf, Matrix<Visibility> a, const BaseLines &p,
+                                 const std::vector<Int> &wbin, const std::vector<Visibility> &v)
+    {
+        int rc = gridhip_comm_convgrid2(comm_, a.h, a.w, reinterpret_cast<double *>(a.data.data()), (Int)v.size(), gcf.W,
+                                        gcf.Q, gcf.gh, gcf.gw, reinterpret_cast<const double *>(gcf.data.data()),
+                                        p.u.data(), p.v.data(), 1, wbin.data(), reinterpret_cast<const double *>(v.data()));
+        if (rc) throw Error(rc, gridhip_comm_last_error(comm_));
+        return a;
+    }
+
+   private:
+    gridhip_comm *comm_ = nullptr;
+};
+
 }  // namespace gridding

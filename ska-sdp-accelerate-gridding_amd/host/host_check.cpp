@@ -1,5 +1,6 @@
 // host_check — exercises gridding.hpp end to end on one GPU and prints checksums that
 // tests/test_gpu_cpp_host.py compares with the CPU oracle on the same generated inputs.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -44,6 +45,16 @@ int main(int argc, char **argv)
             for (Int x = 0; x < N; ++x) { gs += g(y, x) * (double)(1 + (y * 31 + x * 17) % 7); gabs += std::abs(g(y, x)); }
         for (Int k = 0; k < n; ++k) ds += d[k] * (double)(1 + k % 5);
         printf("convgrid2 %.17g %.17g %.17g\n", gs.real(), gs.imag(), gabs);
+        {   // the same through the node interface (a communicator over the devices given; here one)
+            Node node(1);
+            Matrix<Visibility> gn = node.convgrid2(gcf, a, p, wbin, vis);
+            double diff = 0, mx = 0;
+            for (size_t i = 0; i < gn.data.size(); ++i) {
+                diff = std::max(diff, std::abs(gn.data[i] - g.data[i]));
+                mx = std::max(mx, std::abs(g.data[i]));
+            }
+            printf("node %d %.3g\n", node.devices(), diff / mx);
+        }
         printf("degrid2 %.17g %.17g\n", ds.real(), ds.imag());
         // error behaviour: a bad shape is reported, not silently ignored
         try {

@@ -68,3 +68,5 @@ def test_cpp_host_mirror_matches_oracle(tmp_path, oracle):
     assert abs(got_g - gs) / scale < 1e-12
     assert abs(got_d - ds) / (np.abs(d).sum() * 5) < 1e-10
     assert lines["error"] == ["-1"]  # GRIDHIP_EINVAL surfaces as gridding::Error
+    # the node interface (gridhip_comm_*, one device here) gives the same grid up to summation order
+    assert lines["node"][0] == "1" and float(lines["node"][1]) < 1e-12
