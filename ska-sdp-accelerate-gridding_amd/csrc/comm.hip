@@ -209,6 +209,7 @@ int gridhip_comm_allreduce_grids(gridhip_comm *c, int64_t cells, double *const *
     if (cells == 0) return GRIDHIP_OK;
     GH_NCCL(c, g_rccl.GroupStart());
     for (size_t i = 0; i < c->ctx.size(); ++i) {
+        (void)hipSetDevice(c->ctx[i]->device);  // (one thread drives several devices: each call is made on its own)
         const ncclResult_t r = g_rccl.AllReduce(grids[i], grids[i], (size_t)cells * 2, ncclDouble, ncclSum, c->comms[i],
                                                 c->ctx[i]->stream);
         if (r != ncclSuccess) {
