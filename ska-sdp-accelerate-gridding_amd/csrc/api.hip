@@ -108,7 +108,7 @@ int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64
             q.g.py = py;
             q.g.px = px;
             q.g.P = P;
-            q.g.nvis = (int32_t)(n > 0 ? n : 1);
+            q.g.nvis = (int32_t)(n > 0 ? n : 1);  // (nrec stays n * P)
             q.g.nslices = (int32_t)(W * Q * Q * P);
             const bool want = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && q.nrec / (int64_t)q.g.nbins >= 256);
             q.sorted = want && sorted_plan(ctx, q.g, q.block, &q.nkeys, &q.batch, &q.lds_sorted);

@@ -282,14 +282,14 @@ __global__ void aw_relabel_kernel(VisRec *__restrict__ recs, const int32_t *__re
     }
 }
 
-// [1] += [0]: the drops of one batch's binning join the call's total; [28] += the batch's distinct kernels
+// [30] += [0]: the drops of one batch's binning join the call's total; [28] += the batch's distinct kernels
 __global__ void aw_account_kernel(int32_t *__restrict__ scalars, const int32_t *__restrict__ counters, int cache, int32_t m)
 {
-    scalars[1] += scalars[0];
+    scalars[30] += scalars[0];
     scalars[28] += cache ? counters[1] : m;
     scalars[29] += m;
 }
-__global__ void aw_finish_kernel(int32_t *__restrict__ scalars) { scalars[0] = scalars[1]; }
+__global__ void aw_finish_kernel(int32_t *__restrict__ scalars) { scalars[0] = scalars[30]; }
 
 }  // namespace gridhip
 
@@ -326,9 +326,9 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
     if (S > 63 || A > 46340 || n > (int64_t)0x7fffff00 || W * Q * Q >= ((int64_t)1 << 30))
         return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside aw limits");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    // [0] dropped, [1] dropped so far (batches), [2] errors, [28] distinct kernels built, [29] visibilities keyed
+    // [0] dropped, [2] errors, [28] distinct kernels built, [29] visibilities keyed, [30] dropped so far (batches)
     GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(int32_t), ctx->stream));
-    GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 28, 0, 2 * sizeof(int32_t), ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 28, 0, 3 * sizeof(int32_t), ctx->stream));
     if (n == 0) return GRIDHIP_OK;
     const size_t S2 = (size_t)S * S, pairs = (size_t)A * A;
     const int cache = ctx->opt.aw_cache != 0;
@@ -428,6 +428,7 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         mark(ctx, 1);
         // gridding: the pre-pass drops the visibilities whose `ok` is -1 (counted), the tile kernel reads the table
         p.g.nvis = (int32_t)m;
+        p.g.nrec = (int32_t)m;
         GH_CHECK(launch_bin(ctx, p.g, m, bu, bv, uv_stride, ok));
         Tables t = tables_of(ctx, p.g);
         {

@@ -30,7 +30,7 @@
 // Coordinates follow frac_coords / convgrid2 of src/Gridding.hs:126-151,212-218: the footprint origin is
 // (x - gw/2, y - gh/2); a visibility none of whose taps can land inside the grid is dropped here (fixoutofbounds
 // would drop every one of its taps, :883-891).
-#include "common.h"
+#include "tile_common.h"
 
 namespace gridhip {
 
@@ -680,10 +680,8 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
     Tables t = tables_of(ctx, g);
     int32_t *block_hist = nullptr;
-    GH_CHECK_HIP(ctx, hipMemsetAsync(t.bin_count, 0, (size_t)g.nbins * sizeof(int32_t), ctx->stream));
-    // [0] = dropped (wbin out of range), [2] = errors; ([1] belongs to the aw gridders, which bin in batches)
-    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars, 0, sizeof(int32_t), ctx->stream));
-    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 2, 0, sizeof(int32_t), ctx->stream));
+    // scalars: [0] = dropped (wbin out of range), [2] = errors
+    // (cleared together with the histogram and the coarse cursors by one small kernel further down)
     // record slots the scatter may write: all n of them - or fewer under the test hook "fault_inject", which
     // hides the array's last slots so that the bounds checks have something to catch
     const int64_t cap64 = n - (ctx->opt.fault_inject > 0 ? ctx->opt.fault_inject : 0);
@@ -732,7 +730,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         const bool t12 = g.nbins <= TMP12_MAX_BINS && g.T <= 128 && p != 5;
         GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * (t12 ? 12 : 16)));
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));  // coarse cursors
-        GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->blockhist.ptr, 0, (size_t)ncoarse * sizeof(int32_t), ctx->stream));
+        launch_clear(ctx, t.bin_count, g.nbins, t.scalars, 3, (int32_t *)ctx->blockhist.ptr, ncoarse);
         // chunk size: 8192 records, one work-group per CU (option scatter_chunk = 4096: two per CU; measured no faster)
         const bool small_chunk = ctx->opt.scatter_chunk == 4096;
         const int chunk = small_chunk ? 4096 : 8192;
@@ -780,6 +778,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         return GRIDHIP_OK;
     }
 
+    launch_clear(ctx, t.bin_count, g.nbins, t.scalars, 3);
     if (lds_hist) {
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)blocks * g.nbins * sizeof(int32_t)));
         block_hist = (int32_t *)ctx->blockhist.ptr;

@@ -37,6 +37,7 @@ struct Geom {
     int32_t chunk;        // max visibilities per work item
     int32_t dbg;          // ablation switch for tuning runs (0 = off)
     int32_t per_vis;      // 1: the kernel table holds one [gh][gw] slice per visibility (aw gridders)
+    int32_t nrec;         // record slots the pre-pass may have filled (n * P): work items stay inside them
     int32_t nvis;         // visibilities of the call: a record's `orig` is below it
     int32_t nslices;      // [gh][gw] slices in the kernel table: a record's `kslice` is below it
     // Sub-footprints.  A kernel the tap-reusing tile kernel has no instantiation for (supports above 16, non-square
@@ -74,8 +75,8 @@ struct gridhip_ctx {
     gridhip::Workspace blockhist;  // [pre-pass work-groups][nbins] histograms -> first slots
     gridhip::Workspace ktab;       // kernel table cut into zero-padded square parts (sub-footprints, api.hip)
     gridhip::Workspace aw;         // aw gridders: pair slots, pair kernels, key hash table, table of distinct kernels
-    int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [1]=aw drops, [2]=errors, [4..19] work queues,
-                                   // [20..27] clock stamps of the last sorted tile kernel, [32..] profile
+    int32_t *d_scalars = nullptr;  // [0]=dropped (wbin out of range), [2]=errors, [4..19] work queues,
+                                   // [20..27] clock stamps of the last sorted tile kernel, [28..30] aw gridders, [32..] profile
     int num_cu = 256;
     int max_lds = 160 * 1024;
     bool timing = false;

@@ -88,6 +88,7 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->gh = (int32_t)gh;
     g->gw = (int32_t)gw;
     g->nvis = (int32_t)(n > 0 ? n : 1);
+    g->nrec = g->nvis;
     g->nslices = (int32_t)(W * Q * Q);
     g->fgh = (int32_t)gh;
     g->fgw = (int32_t)gw;

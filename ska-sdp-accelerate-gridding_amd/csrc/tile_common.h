@@ -15,7 +15,9 @@ __device__ __forceinline__ bool find_work_at(const Geom &g, const int32_t *__res
                                              const int32_t *__restrict__ work_start, int grp, int k, WorkItem *w)
 {
     const int32_t *ws = work_start + (size_t)grp * (g.ntiles + 1);
-    if (k >= ws[g.ntiles]) return false;
+    // (a group never has more items than every tile's partial chunk plus the full chunks the records make: whatever
+    // the table says, the queue ends)
+    if (k >= ws[g.ntiles] || k > g.nrec / g.chunk + g.ntiles) return false;
     int lo = 0, hi = g.ntiles;  // largest t with ws[t] <= k
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -25,8 +27,9 @@ __device__ __forceinline__ bool find_work_at(const Geom &g, const int32_t *__res
             hi = mid;
     }
     const int bin = grp * g.ntiles + lo;
-    const int c = k - ws[lo], nch = ws[lo + 1] - ws[lo];
-    const int b0 = bin_start[bin], cnt = bin_start[bin + 1] - b0;
+    const int nch = max(ws[lo + 1] - ws[lo], 1), c = min(max(k - ws[lo], 0), nch - 1);
+    // (the tables are the pre-pass's own, but nothing read from memory becomes an index before it is in range)
+    const int b0 = min(max(bin_start[bin], 0), g.nrec), cnt = min(max(bin_start[bin + 1] - b0, 0), g.nrec - b0);
     w->tile = lo;
     w->v_lo = b0 + (int)(((int64_t)cnt * c) / nch);
     w->v_hi = b0 + (int)(((int64_t)cnt * (c + 1)) / nch);
@@ -119,6 +122,18 @@ static inline int work_blocks(const Geom &g, int64_t n)
     // per group: every tile may add one partial chunk
     int64_t per_group = n / g.chunk + g.ntiles + 1;
     return (int)(per_group * g.ngroups);
+}
+
+// Zeroes up to three int32 ranges in one launch.  Kernels, not hipMemsetAsync: what a gridding call enqueues is then
+// nothing but kernel launches, which a caller may capture into a HIP graph and replay.
+__global__ void __launch_bounds__(256) clear_ints_kernel(int32_t *a, int na, int32_t *b, int nb, int32_t *c, int nc);
+static inline void launch_clear(gridhip_ctx *ctx, int32_t *a, int na, int32_t *b = nullptr, int nb = 0, int32_t *c = nullptr,
+                                int nc = 0)
+{
+    const int most = na > nb ? (na > nc ? na : nc) : (nb > nc ? nb : nc);
+    int blocks = (most + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(clear_ints_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a, na, b, nb, c, nc);
 }
 
 template <typename K>

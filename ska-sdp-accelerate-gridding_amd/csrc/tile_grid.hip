@@ -18,6 +18,15 @@
 
 namespace gridhip {
 
+__global__ void __launch_bounds__(256) clear_ints_kernel(int32_t *a, int na, int32_t *b, int nb, int32_t *c, int nc)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na || i < nb || i < nc; i += gridDim.x * blockDim.x) {
+        if (i < na) a[i] = 0;
+        if (i < nb) b[i] = 0;
+        if (i < nc) c[i] = 0;
+    }
+}
+
 // Lane -> tap mapping: tap t = step*64 + lane, (i, j) = (t / gw, t % gw).  Taps of one slice
 // are contiguous in memory, so a step reads one coalesced 1 KiB run; with the LDS row pitch
 // congruent to gw modulo 32 (ctx.hip) tap t falls on 8-byte bank pair t mod 32, so the 32

@@ -624,8 +624,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     GH_CHECK(ws_reserve(ctx, ctx->sorted, (size_t)nblk * 2 * batch * 24));
     double2 *svals = (double2 *)ctx->sorted.ptr;
     uint2 *smo = (uint2 *)(svals + (size_t)nblk * 2 * batch);
-    GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 4, 0, 16 * sizeof(int32_t), ctx->stream));  // the w-groups' queues
-    if (g.dbg & 16) GH_CHECK_HIP(ctx, hipMemsetAsync(t.scalars + 32, 0, 64 * sizeof(int32_t), ctx->stream));
+    launch_clear(ctx, t.scalars + 4, 16, (g.dbg & 16) ? t.scalars + 32 : nullptr, (g.dbg & 16) ? 64 : 0);  // the w-groups' queues
 #define GH_LAUNCH(S_, D_)                                                                                        \
     do {                                                                                                         \
         GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_>));                                               \

@@ -429,6 +429,47 @@ def test_device_path_is_ordered_with_the_callers_stream(ctx):
     assert abs((s1 - G2.sum()).item()) / G2.abs().sum().item() < 1e-12
 
 
+@pytest.mark.parametrize("prepass,S", [(1, 7), (2, 15), (2, 21)])
+def test_device_path_can_be_captured_into_a_hip_graph(ctx, prepass, S):
+    """After a warm-up call (scratch sized, LDS limits raised) a device-pointer gridding call enqueues nothing but
+    kernel launches on the caller's stream - no hipMemsetAsync (memset nodes captured from small, odd-sized memsets
+    did not replay correctly on ROCm 7.2), no allocation, no synchronisation - so the caller can capture it and replay
+    it.  Three replays, each onto a cleared grid, must reproduce the eager result (every replay re-clears and refills
+    the pre-pass tables)."""
+    import torch
+    dev = torch.device("cuda:0")
+    N, W, Q, n = 320, 8, 4, 150000
+    gcf, u, v, wb, vis = case(91 + S, N, N, W, Q, S, S, n, spread=0.55)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tg, tu, tv, twb, tvis = t(gcf), t(u), t(v), t(wb), t(vis)
+    try:
+        ctx.set_option("prepass", prepass)
+        ctx.set_option("sort", 1)
+        ref = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+        ctx.convgrid2(tg, ref, (tu, tv, None), twb, tvis)
+        torch.cuda.synchronize()
+        G = torch.zeros_like(ref)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            ctx.convgrid2(tg, G, (tu, tv, None), twb, tvis)  # warm-up on the capture stream
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            ctx.convgrid2(tg, G, (tu, tv, None), twb, tvis)
+        torch.cuda.synchronize()
+        errs = []
+        for _ in range(3):
+            G.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            errs.append(((G - ref).abs().max() / ref.abs().max()).item())
+        errors = ctx.get_option("errors")
+    finally:
+        ctx.set_option("prepass", 0)
+        ctx.set_option("sort", 0)
+    assert max(errs) < 1e-12 and errors == 0
+
+
 @pytest.mark.parametrize("mode,n", [(1, 20000), (2, 200000), (4, 200000), (5, 200000), (3, 20000)])
 def test_record_writes_are_bounded_by_the_array(ctx, oracle, mode, n):
     """Every record store of the pre-pass is checked against the record array's capacity.  The test hook
