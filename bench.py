@@ -468,6 +468,8 @@ def main():
             # dominant kernel: the per-key aw-kernel build (fp64 vector ALU): (2S-1)^2-bounded 'same' convolutions
             info = ctx.aw_stats(S)
             flops = info["conv_flops_per_call"]
+            if n > (1 << 22):  # the library works in batches of 2^22 visibilities and its events time the first one
+                flops *= (1 << 22) / n
             peak = cus * FP64_VALU_FLOP_PER_CLK_CU * nominal_ghz / 1e3  # TFLOP/s
             build_ms = float(np.mean(pre_ms))  # pair kernels + keys + aw_build_kernel (the last dominates)
             achieved = flops / (build_ms * 1e-3) / 1e12 if build_ms > 0 else 0.0
