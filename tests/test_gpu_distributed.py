@@ -131,3 +131,67 @@ def test_bench_default_line_is_bounded():
     assert 0 < r["frac"] <= 1 and 0 < r["lds_floor_frac"] <= 1 and r["kernel_ms"]["min"] <= r["kernel_ms"]["median"]
     assert rec["cpu_baseline"]["cores"] >= 1 and len(rec["cpu_baseline"]["modes"]) == 3
     assert rec["cpu_baseline"]["cpu_model"] and rec["value"] > 0
+
+
+def test_two_ranks_share_one_gpu_over_gloo():
+    """Two real rank processes (both on cuda:0 - NCCL refuses two ranks on one device, so the collective is gloo's, which
+    stages cuda tensors through the host): each grids its shard of the stream through OverlappedGridReducer for four
+    steps; every reduced grid must equal the oracle's grid of the whole stream.  This is the N > 1 control flow
+    (sharding, buffer clearing, side-stream ordering, waiting on the previous reduction) with two ranks that
+    really run concurrently."""
+    body = textwrap.dedent(f"""
+        import os, sys, json
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "ska-sdp-accelerate-gridding_amd", "python"))
+        import numpy as np, torch, torch.distributed as dist
+        rank, world = int(os.environ["RANK"]), 2
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda", 0)
+        import gridhip
+        from gridhip.distributed import OverlappedGridReducer, shard_bounds
+        from oracle import gridref_c
+        rng = np.random.default_rng(21)                      # the same stream on both ranks
+        N, W, Q, S, n = 160, 4, 4, 7, 30001
+        gcf = rng.normal(size=(W, Q, Q, S, S)) + 1j * rng.normal(size=(W, Q, Q, S, S))
+        steps = [(rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)) for _ in range(4)]
+        wb = rng.integers(0, W, n)
+        vis = rng.normal(size=n) + 1j * rng.normal(size=n)
+        lo, hi = shard_bounds(n, world, rank)
+        T = lambda a: torch.as_tensor(a, device=dev)
+        ctx = gridhip.Context(0)
+        bufs = [torch.zeros((N, N), dtype=torch.complex128, device=dev) for _ in range(2)]
+        red = OverlappedGridReducer(bufs)
+        errs = []
+        def check(i):
+            if red.work[i % 2] is not None:
+                red.work[i % 2].wait()
+            torch.cuda.synchronize()
+            ref = gridref_c.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), steps[i][0], steps[i][1], wb, vis)
+            errs.append(float(np.abs(bufs[i % 2].cpu().numpy() - ref).max() / np.abs(ref).max()))
+        for i in range(4):
+            g = red.begin(i)
+            ctx.convgrid2(T(gcf), g, (T(steps[i][0][lo:hi]), T(steps[i][1][lo:hi]), None), T(wb[lo:hi]), T(vis[lo:hi]))
+            red.end(i)
+            if i >= 1:
+                check(i - 1)
+        red.finish()
+        check(3)
+        print(json.dumps({{"rank": rank, "errs": errs, "errors": ctx.get_option("errors")}}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+    """)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK",)}
+        env.update(RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", body], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    for so, _ in outs:
+        rec = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+        assert len(rec["errs"]) == 4 and max(rec["errs"]) < 1e-10 and rec["errors"] == 0
