@@ -257,8 +257,10 @@ __global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec 
                 if (t < S2) {
                     const int a = lbase + i * g.ldw + j;
                     const double gr = lre[a], gi = lim[a];
-                    sr += kv.x * gr - kv.y * gi;
-                    si += kv.x * gi + kv.y * gr;
+                    sr = fma(kv.x, gr, sr);
+                    sr = fma(-kv.y, gi, sr);
+                    si = fma(kv.x, gi, si);
+                    si = fma(kv.y, gr, si);
                 }
                 j += dj;
                 i += di;

@@ -414,8 +414,12 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                                     const double *cell = lre + (lbase + loff[s]);
                                     if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
                                         const double gr = cell[0], gi = cell[SORTED_IM_OFF / 8];
-                                        sr[q] += k[s].x * gr - k[s].y * gi;
-                                        si[q] += k[s].x * gi + k[s].y * gr;
+                                        // four FMAs (written out: `sr += a*b - c*d` compiles to two multiplies, an
+                                        // FMA and an add per component, and this loop is bound by vector-ALU issue)
+                                        sr[q] = fma(k[s].x, gr, sr[q]);
+                                        sr[q] = fma(-k[s].y, gi, sr[q]);
+                                        si[q] = fma(k[s].x, gi, si[q]);
+                                        si[q] = fma(k[s].y, gr, si[q]);
                                     }
                                 }
                             }
