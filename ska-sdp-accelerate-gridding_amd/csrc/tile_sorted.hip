@@ -396,6 +396,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                 } else {
                     // four visibilities of the run at a time: their partial sums are reduced across the wave
                     // together (wave_sum4_rows), the results land in lanes 15, 31, 47 and 63
+                    // (last step's taps with zeros in the lanes that have none)
+                    const double2 kz = tail_ok ? k[NSTEP - 1] : make_double2(0.0, 0.0);
                     for (int i = 0; i < len; i += 4) {
                         double sr[4], si[4];
                         int32_t oo[4];
@@ -409,18 +411,26 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                                 const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mo.x, j);
                                 const int lbase = (int)(m & 0xffff);
                                 oo[q] = __builtin_amdgcn_readlane((int)mo.y, j);
+                                // all of the visibility's tile cells first (2 x NSTEP LDS reads in flight), then the
+                                // products: the reads' latency is paid once per visibility, not once per step.  The
+                                // lanes without a tap in the last step read their first cell again and multiply by a
+                                // zero tap (kz) instead of being switched off.
+                                double gr[NSTEP], gi[NSTEP];
 #pragma unroll
                                 for (int s = 0; s < NSTEP; ++s) {
                                     const double *cell = lre + (lbase + loff[s]);
-                                    if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
-                                        const double gr = cell[0], gi = cell[SORTED_IM_OFF / 8];
-                                        // four FMAs (written out: `sr += a*b - c*d` compiles to two multiplies, an
-                                        // FMA and an add per component, and this loop is bound by vector-ALU issue)
-                                        sr[q] = fma(k[s].x, gr, sr[q]);
-                                        sr[q] = fma(-k[s].y, gi, sr[q]);
-                                        si[q] = fma(k[s].x, gi, si[q]);
-                                        si[q] = fma(k[s].y, gr, si[q]);
-                                    }
+                                    gr[s] = cell[0];
+                                    gi[s] = cell[SORTED_IM_OFF / 8];
+                                }
+#pragma unroll
+                                for (int s = 0; s < NSTEP; ++s) {
+                                    const double2 kk = (s == NSTEP - 1 && TAIL != 64) ? kz : k[s];
+                                    // four FMAs (written out: `sr += a*b - c*d` compiles to two multiplies, an
+                                    // FMA and an add per component, and this loop is bound by vector-ALU issue)
+                                    sr[q] = fma(kk.x, gr[s], sr[q]);
+                                    sr[q] = fma(-kk.y, gi[s], sr[q]);
+                                    si[q] = fma(kk.x, gi[s], si[q]);
+                                    si[q] = fma(kk.y, gr[s], si[q]);
                                 }
                             }
                         }
