@@ -71,7 +71,8 @@ int gridhip_reset_stream(gridhip_ctx *ctx);
 void *gridhip_get_stream(gridhip_ctx *ctx);
 int gridhip_synchronize(gridhip_ctx *ctx);
 /* Tuning knobs (all have defaults chosen per shape):
- *   "tile"      grid-tile side T in cells (power of two, 8..128; 0 = auto)
+ *   "tile"      side of a square grid tile in cells (8..128; 0 = auto: the largest rectangle whose planes fit the
+ *               LDS layout, 65 x 89 cells for a 15 x 15 kernel); "tile_x" / "tile_y": a rectangular tile
  *   "block"     threads per work-group of the tile kernels (multiple of 64, <=1024; 0 = auto)
  *   "chunk"     max visibilities per work item (0 = auto; the sorted kernel takes at most 16384)
  *   "wgroups"   number of w-plane groups work items are split into for XCD/L2 locality (1..16; 0 = auto)

@@ -80,8 +80,9 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
         return o;
     }
     const int32_t X = (int32_t)x0 + g.offx, Y = (int32_t)y0 + g.offy;
-    const int32_t tx = X >> g.tshift, ty = Y >> g.tshift;  // X, Y >= 0 by construction of offx/offy
-    const int32_t lx = X & (g.T - 1), ly = Y & (g.T - 1);
+    // (X, Y >= 0 by construction of offx / offy)
+    const int32_t tx = (int32_t)((uint32_t)X / (uint32_t)g.Tx), ty = (int32_t)((uint32_t)Y / (uint32_t)g.Ty);
+    const int32_t lx = X - tx * g.Tx, ly = Y - ty * g.Ty;
     const int32_t grp = ((int32_t)wb * g.ngroups) / g.W;  // 32-bit: W * ngroups < 2^31
     o.bin = grp * g.ntiles + ty * g.ntx + tx;
     o.lxy = (ly << 16) | lx;
@@ -727,7 +728,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
     const bool two_level = lds_hist && (p == 2 || p == 4 || p == 5 || (p == 0 && n >= ((int64_t)1 << 22)));
     if (two_level) {
-        const bool t12 = g.nbins <= TMP12_MAX_BINS && g.T <= 128 && p != 5;
+        const bool t12 = g.nbins <= TMP12_MAX_BINS && p != 5;  // (tile sides <= 128: lx, ly take 7 bits each)
         GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * (t12 ? 12 : 16)));
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));  // coarse cursors
         launch_clear(ctx, t.bin_count, g.nbins, t.scalars, 3, (int32_t *)ctx->blockhist.ptr, ncoarse);
@@ -740,7 +741,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         // pre-records: when bin | lx | ly | kslice fit one 64-bit word
         const int bb = bits_for(g.nbins);
         const int64_t nslices = g.nslices;
-        const bool use_pre = p != 4 && g.T <= 128 && bb + 14 + bits_for(nslices) <= 63;
+        const bool use_pre = p != 4 && bb + 14 + bits_for(nslices) <= 63;
         unsigned long long *pre = nullptr;
         if (use_pre) {
             GH_CHECK(ws_reserve(ctx, ctx->recs_raw, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));

@@ -25,8 +25,7 @@ static_assert(sizeof(VisRec) == 12, "VisRec must be 12 bytes");
 struct Geom {
     int64_t H, Wd;        // grid rows, columns
     int32_t W, Q, gh, gw; // kernel table dims
-    int32_t T;            // tile side (cells), power of two
-    int32_t tshift;       // log2(T)
+    int32_t Tx, Ty;       // tile width / height (cells, each <= 128; any size: the binning divides)
     int32_t offx, offy;   // coordinate offsets so tile indices start at 0
     int32_t ntx, nty;     // tiles per row / column
     int32_t ntiles;       // ntx*nty
@@ -49,7 +48,7 @@ struct Geom {
 };
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0;
 };
 
 struct Workspace {

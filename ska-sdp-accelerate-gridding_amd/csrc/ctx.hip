@@ -95,30 +95,60 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->px = g->py = g->P = 1;
 
     const size_t lds_cap = (size_t)ctx->max_lds - 1024;
-    int T = (int)ctx->opt.tile;
-    auto lds_for = [&](int t) {
-        int lcols = t + (int)gw - 1, lrows = t + (int)gh - 1;
-        return (size_t)lds_pitch(lcols, (int)gw) * lrows * 16;
+    // one plane (re or im) of the tap-reusing kernel's tile must fit below the fixed re / im distance (tile_sorted.hip)
+    constexpr size_t PLANE_CAP = 65528;
+    auto plane_for = [&](int tx, int ty) {
+        return (size_t)lds_pitch(tx + (int)gw - 1, (int)gw) * (size_t)(ty + (int)gh - 1) * 8;
     };
-    if (T == 0) {
-        T = 64;
-        while (T > 8 && lds_for(T) > lds_cap) T >>= 1;
-        // small grids: keep enough tiles to occupy the chip
-        while (T > 16 && ((H + T - 1) / T) * ((Wd + T - 1) / T) < 1024) T >>= 1;
+    int Tx = (int)ctx->opt.tile_x, Ty = (int)ctx->opt.tile_y;
+    if (ctx->opt.tile) Tx = Ty = (int)ctx->opt.tile;  // option "tile": a square tile
+    if ((Tx == 0) != (Ty == 0)) return fail(ctx, GRIDHIP_EINVAL, "tile_x and tile_y go together");
+    if (Tx == 0) {
+        // The largest tile whose planes fit: tap reuse per work item grows with the tile's area (visibilities per
+        // distinct kernel slice = n / (tiles W Q^2)) and the halo's share shrinks.  The row pitch comes in steps of
+        // 32 cells (bank-conflict rule, lds_pitch), so the candidates are the widest tile of each pitch with the
+        // tallest height that fits: 65 x 89 for a 15 x 15 kernel, against 64 x 64 as a square power of two.
+        size_t best = 0;
+        for (int tx = 8; tx <= 128; ++tx) {
+            const int pitch = lds_pitch(tx + (int)gw - 1, (int)gw);
+            if (tx < 128 && lds_pitch(tx + 1 + (int)gw - 1, (int)gw) == pitch) continue;  // (not the widest of its pitch)
+            int rows = (int)(PLANE_CAP / ((size_t)pitch * 8));
+            if ((size_t)rows * pitch * 16 > lds_cap - 24576) rows = (int)((lds_cap - 24576) / ((size_t)pitch * 16));  // room for the sort's histogram
+            int ty = rows - ((int)gh - 1);
+            if (ty > 128) ty = 128;
+            if (ty < 8) continue;
+            if ((size_t)tx * ty > best) {
+                best = (size_t)tx * ty;
+                Tx = tx;
+                Ty = ty;
+            }
+        }
+        if (best == 0) {
+            Tx = Ty = 8;
+            if (plane_for(8, 8) * 2 > lds_cap)
+                return fail(ctx, GRIDHIP_EUNSUPPORTED, "a %lldx%lld kernel does not fit an LDS tile", (long long)gh, (long long)gw);
+        }
+        // small grids: keep enough tiles to occupy the chip (shrink the longer side, a cell at a time)
+        while ((Tx > 16 || Ty > 16) && ((H + Ty - 1) / Ty) * ((Wd + Tx - 1) / Tx) < 1024) {
+            if (Ty >= Tx)
+                --Ty;
+            else
+                --Tx;
+        }
     }
-    if (T < 8 || T > 128 || (T & (T - 1))) return fail(ctx, GRIDHIP_EINVAL, "tile must be a power of two in 8..128");
-    if (lds_for(T) > lds_cap)
-        return fail(ctx, GRIDHIP_EUNSUPPORTED, "tile %d with %lldx%lld kernel needs %zu B of LDS", T,
-                    (long long)gh, (long long)gw, lds_for(T));
-    g->T = T;
-    g->tshift = ilog2(T);
-    g->lcols = T + (int)gw - 1;
-    g->lrows = T + (int)gh - 1;
+    if (Tx < 8 || Tx > 128 || Ty < 8 || Ty > 128) return fail(ctx, GRIDHIP_EINVAL, "tile sides must be in 8..128");
+    if (plane_for(Tx, Ty) * 2 > lds_cap)
+        return fail(ctx, GRIDHIP_EUNSUPPORTED, "tile %dx%d with %lldx%lld kernel needs %zu B of LDS", Tx, Ty,
+                    (long long)gh, (long long)gw, plane_for(Tx, Ty) * 2);
+    g->Tx = Tx;
+    g->Ty = Ty;
+    g->lcols = Tx + (int)gw - 1;
+    g->lrows = Ty + (int)gh - 1;
     g->ldw = lds_pitch(g->lcols, (int)gw);
-    g->offx = (((int)gw - 1 + T - 1) / T) * T;
-    g->offy = (((int)gh - 1 + T - 1) / T) * T;
-    g->ntx = (int)((Wd - 1 + g->offx) / T) + 1;
-    g->nty = (int)((H - 1 + g->offy) / T) + 1;
+    g->offx = (((int)gw - 1 + Tx - 1) / Tx) * Tx;
+    g->offy = (((int)gh - 1 + Ty - 1) / Ty) * Ty;
+    g->ntx = (int)((Wd - 1 + g->offx) / Tx) + 1;
+    g->nty = (int)((H - 1 + g->offy) / Ty) + 1;
     if ((int64_t)g->ntx * g->nty > (1 << 24)) return fail(ctx, GRIDHIP_EUNSUPPORTED, "too many tiles");
     g->ntiles = g->ntx * g->nty;
 
@@ -146,7 +176,7 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->chunk = chunk;
     g->dbg = (int32_t)ctx->opt.dbg;
 
-    *lds_bytes = lds_for(T);
+    *lds_bytes = plane_for(Tx, Ty) * 2;
     int b = (int)ctx->opt.block;
     if (b == 0) {
         // one work-group per CU at T=64 (LDS-limited): use all 16 waves; smaller tiles
@@ -283,6 +313,8 @@ int gridhip_synchronize(gridhip_ctx *ctx)
 static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
 {
     if (!strcmp(key, "tile")) return &ctx->opt.tile;
+    if (!strcmp(key, "tile_x")) return &ctx->opt.tile_x;
+    if (!strcmp(key, "tile_y")) return &ctx->opt.tile_y;
     if (!strcmp(key, "block")) return &ctx->opt.block;
     if (!strcmp(key, "chunk")) return &ctx->opt.chunk;
     if (!strcmp(key, "wgroups")) return &ctx->opt.wgroups;

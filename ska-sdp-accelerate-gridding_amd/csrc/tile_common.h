@@ -53,7 +53,7 @@ __device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int 
     const int32_t *p = reinterpret_cast<const int32_t *>(recs + idx);
     const int32_t a = p[0], k = p[1], o = p[2];
     VisRec r;
-    const int32_t lx = min(a & 0xffff, g.T - 1), ly = min((a >> 16) & 0xffff, g.T - 1);
+    const int32_t lx = min(a & 0xffff, g.Tx - 1), ly = min((a >> 16) & 0xffff, g.Ty - 1);
     r.lxy = (ly << 16) | lx;
     r.kslice = min(max(k, 0), g.nslices - 1);
     r.orig = min(max(o, 0), g.nvis - 1);

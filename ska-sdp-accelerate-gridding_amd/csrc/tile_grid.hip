@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
 
     // flush the cells that exist in the grid
     const int tx = w.tile % g.ntx, ty = w.tile / g.ntx;
-    const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
+    const int64_t ox = (int64_t)tx * g.Tx - g.offx, oy = (int64_t)ty * g.Ty - g.offy;
     const int ncell = g.lrows * g.lcols;
     // Consecutive lanes take (re, im) of consecutive cells, so one atomic instruction covers a
     // contiguous 512-byte run of the interleaved grid row (memory-side fp64 atomics run at full rate
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec 
     const int plane = g.lrows * g.ldw;
     double *lre = lds, *lim = lds + plane;
     const int tx = w.tile % g.ntx, ty = w.tile / g.ntx;
-    const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
+    const int64_t ox = (int64_t)tx * g.Tx - g.offx, oy = (int64_t)ty * g.Ty - g.offy;
     const int ncell = g.lrows * g.lcols;
     for (int c = tid; c < ncell; c += blockDim.x) {
         const int r_ = c / g.lcols, c_ = c - r_ * g.lcols;

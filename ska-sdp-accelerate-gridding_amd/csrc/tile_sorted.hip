@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
         const int first_plane = (d.grp * g.W + g.ngroups - 1) / g.ngroups;
         const int first_slice = first_plane * g.Q * g.Q * g.P;
         const int tx = d.tile % g.ntx, ty = d.tile / g.ntx;
-        const int64_t ox = (int64_t)tx * g.T - g.offx, oy = (int64_t)ty * g.T - g.offy;
+        const int64_t ox = (int64_t)tx * g.Tx - g.offx, oy = (int64_t)ty * g.Ty - g.offy;
         if (DEGRID) {
             const double2 *gsrc = reinterpret_cast<const double2 *>(grid);
             for (int c = tid; c < ncell; c += nthr) {
@@ -599,7 +599,6 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
 {
     // square supports with a compile-time instantiation below
     if (g.gh != g.gw || g.gh < 5 || g.gh > 16) return false;
-    if (g.T > 128) return false;
     const int planes = (g.W + g.ngroups - 1) / g.ngroups + 1;  // groups differ by at most one plane
     // (aw gridders: the sort is by kslice mod 4096)
     const int64_t keys = g.per_vis ? 4096 : (int64_t)planes * g.Q * g.Q * g.P;
