@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
                                                          int32_t *__restrict__ bin_count,
                                                          int32_t *__restrict__ block_hist,
                                                          int32_t *__restrict__ scalars, int bin_lo, int bin_hi,
-                                                         PreFmt pf, unsigned long long *__restrict__ pre)
+                                                         PreFmt pf, unsigned long long *__restrict__ pre,
+                                                         double2 *__restrict__ zero_out)
 {
     // LDS_HIST: this launch handles the bins [bin_lo, bin_hi) only (a window that fits in LDS); grids
     // with more bins than that are covered by several launches.  pre != null: the first window's launch leaves
@@ -223,8 +224,12 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
             for (int q = 0; q < UN; ++q) {
                 const int64_t e = k0 + (int64_t)q * blockDim.x;
                 b[q] = vis_bin(g, pu[q], pv[q], wb[q], kk[q], part[q]);
-                if (e >= hi) b[q].bin = -1;
-                else if (pre) pre[e] = pre_pack(rf, b[q]);
+                if (e >= hi)
+                    b[q].bin = -1;
+                else {
+                    if (pre) pre[e] = pre_pack(rf, b[q]);
+                    if (zero_out && b[q].bin < 0) zero_out[kk[q]] = make_double2(0.0, 0.0);
+                }
             }
         }
 #pragma unroll
@@ -675,7 +680,7 @@ static int launch_two_level(gridhip_ctx *ctx, const Geom &g, const Tables &t, in
 }
 
 int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
-               int64_t uv_stride, const int64_t *wbin)
+               int64_t uv_stride, const int64_t *wbin, double2 *zero_out)
 {
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
@@ -752,11 +757,11 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             if (ctx->opt.count_unroll == 4)
                 hipLaunchKernelGGL((bin_count_kernel<true, 4>), dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
                                    uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
-                                   PreFmt{wdw == 0 ? bb : -bb}, pre);
+                                   PreFmt{wdw == 0 ? bb : -bb}, pre, zero_out);
             else
                 hipLaunchKernelGGL((bin_count_kernel<true, 1>), dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
                                    uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
-                                   PreFmt{wdw == 0 ? bb : -bb}, pre);
+                                   PreFmt{wdw == 0 ? bb : -bb}, pre, zero_out);
         }
         hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                            t.work_start, t.cursor);
@@ -787,12 +792,12 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
             hipLaunchKernelGGL(bin_count_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u,
                                v, uv_stride, wbin, t.bin_count, block_hist, t.scalars, b_lo, b_hi, PreFmt{0},
-                               (unsigned long long *)nullptr);
+                               (unsigned long long *)nullptr, zero_out);
         }
     } else {
         hipLaunchKernelGGL(bin_count_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
                            uv_stride, wbin, t.bin_count, block_hist, t.scalars, 0, g.nbins, PreFmt{0},
-                           (unsigned long long *)nullptr);
+                           (unsigned long long *)nullptr, zero_out);
     }
     hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                        t.work_start, t.cursor);

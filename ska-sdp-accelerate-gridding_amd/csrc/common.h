@@ -157,8 +157,10 @@ __device__ __forceinline__ void frac_coord_dev(int64_t n, int32_t qpx, double p,
 }
 
 // kernel launchers (each enqueues on ctx->stream)
+// zero_out (degrid2): the counting sweep writes a zero prediction for every visibility it drops (no tap inside the
+// grid, wbin out of range), so that the caller's array needs no clearing pass
 int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, const double *v,
-               int64_t uv_stride, const int64_t *wbin);
+               int64_t uv_stride, const int64_t *wbin, double2 *zero_out = nullptr);
 int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int64_t n,
                      const double *gcf, const double *vis, double *grid);
 bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, int *maxchunk, size_t *lds_bytes);

@@ -14,6 +14,7 @@ struct gridhip_plan {
     gridhip::Prep p;
     gridhip::Workspace recs, tables;
     int64_t n = 0;
+    bool all_binned = false;  // no visibility was dropped: degrid writes every element of its output
 };
 
 using namespace gridhip;
@@ -63,6 +64,14 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
         rc = ws_reserve(ctx, ctx->tables, tables_bytes(p->p.g));
         if (rc == GRIDHIP_OK) rc = ws_reserve(ctx, ctx->recs, (size_t)(p->p.nrec > 0 ? p->p.nrec : 1) * sizeof(VisRec));
         if (rc == GRIDHIP_OK) rc = launch_bin(ctx, p->p.g, p->p.nrec, u, v, uv_stride, wbin);
+        if (rc == GRIDHIP_OK && p->p.g.P == 1 && n > 0) {
+            // how many visibilities found a bin: when all did, degrid passes skip clearing their output
+            int32_t binned = 0;
+            const Tables t = tables_of(ctx, p->p.g);
+            if (hipMemcpyAsync(&binned, t.bin_start + p->p.g.nbins, sizeof(binned), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess)
+                p->all_binned = binned == (int32_t)n && ctx->opt.fault_inject == 0;
+        }
     }
     if (rc != GRIDHIP_OK) {
         gridhip_plan_destroy(p);
@@ -109,7 +118,7 @@ int gridhip_plan_degrid_dev(gridhip_plan *p, const double *gcf, const double *gr
     if (!gcf || !grid || (p->n > 0 && !vis_out)) return fail(ctx, GRIDHIP_EINVAL, "null pointer");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     if (p->n == 0) return GRIDHIP_OK;
-    GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)p->n * 16, ctx->stream));
+    if (!p->all_binned) GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)p->n * 16, ctx->stream));
     const double *tk = gcf;
     GH_CHECK(tile_kernels(ctx, p->p, gcf, &tk));
     Lend lend(p);

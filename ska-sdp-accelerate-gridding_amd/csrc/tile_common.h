@@ -50,8 +50,9 @@ __device__ __forceinline__ bool find_work(const Geom &g, const int32_t *__restri
 // cost a wrong sum but never a wild access.
 __device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int idx, const Geom &g, bool *clamped = nullptr)
 {
+    // (streamed once or twice and never again: non-temporal, so that the records do not push kernel taps out of L2)
     const int32_t *p = reinterpret_cast<const int32_t *>(recs + idx);
-    const int32_t a = p[0], k = p[1], o = p[2];
+    const int32_t a = __builtin_nontemporal_load(p), k = __builtin_nontemporal_load(p + 1), o = __builtin_nontemporal_load(p + 2);
     VisRec r;
     const int32_t lx = min(a & 0xffff, g.Tx - 1), ly = min((a >> 16) & 0xffff, g.Ty - 1);
     r.lxy = (ly << 16) | lx;
@@ -59,6 +60,16 @@ __device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int 
     r.orig = min(max(o, 0), g.nvis - 1);
     if (clamped) *clamped = r.lxy != a || r.kslice != k || r.orig != o;
     return r;
+}
+
+// A 16-byte load with the non-temporal hint: the sorter's gather of visibility values, each used once (measured with
+// the records' hint: tile kernel 11.5 -> 11.3 ms, HBM traffic 34.5 -> 31.8 GB per launch, TCC hit rate 53 -> 60 %; the
+// same hint on the walkers' reads of the sorted list measured slower, on its stores 4 % slower)
+typedef double dvec2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_nt(const double2 *p)
+{
+    const dvec2_t v = __builtin_nontemporal_load(reinterpret_cast<const dvec2_t *>(p));
+    return make_double2(v.x, v.y);
 }
 
 // Sum of x over the 64 lanes, valid in lane 63.  Data-parallel-primitive moves only (no LDS

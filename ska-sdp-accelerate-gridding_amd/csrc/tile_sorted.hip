@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
             for (int q = 0; q < 8; ++q) rec[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1), g, &off[q]);
             if (!DEGRID) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) val[q] = (ABL & 8) ? make_double2(1.0, (double)q) : vis[rec[q].orig];
+                for (int q = 0; q < 8; ++q) val[q] = (ABL & 8) ? make_double2(1.0, (double)q) : load_nt(vis + rec[q].orig);
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {

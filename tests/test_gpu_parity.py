@@ -296,6 +296,49 @@ def test_degrid2_matches_oracle(ctx, oracle, N, M, W, Q, gh, gw, n):
     assert rel(got, ref) < TOL
 
 
+@pytest.mark.parametrize("prepass", [0, 2])
+def test_degrid2_writes_zero_for_dropped_visibilities(ctx, oracle, prepass):
+    """degrid2 does not clear its output array: the counting sweep writes the zero prediction of every visibility
+    it drops (no tap inside the grid, NaN coordinates, wbin outside [0, W)) and the tile kernel writes the rest.
+    The output starts as NaN here, so an element nobody wrote would show.  Also through plans: with drops (the
+    plan clears), without (it does not)."""
+    import torch
+    N, W, Q, S, n = 256, 8, 4, 9, 50000
+    gcf, u, v, wb, vis = case(404, N, N, W, Q, S, S, n, spread=0.62)
+    u[5], v[7] = np.nan, np.inf
+    wb[11], wb[13] = -1, W
+    rng = np.random.default_rng(8)
+    G = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    keep = (wb >= 0) & (wb < W) & np.isfinite(u) & np.isfinite(v)
+    ref = np.zeros(n, dtype=np.complex128)
+    ref[keep] = oracle.degrid2(gcf, G, u[keep], v[keep], wb[keep])
+    assert (ref == 0).sum() > 100      # the case really has dropped visibilities
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    nan = lambda: torch.full((n,), float("nan"), dtype=torch.complex128, device=dev)
+    try:
+        ctx.set_option("prepass", prepass)
+        out = nan()
+        ctx.degrid2(t(gcf), t(G), (t(u), t(v), None), t(wb), out)
+        plan = ctx.plan((N, N), gcf.shape, (t(u), t(v), None), t(wb))
+        pout = nan()
+        plan.degrid(t(gcf), t(G), pout)
+        plan.close()
+        inside = np.abs(u) < 0.4
+        inside &= (np.abs(v) < 0.4) & keep
+        plan = ctx.plan((N, N), gcf.shape, (t(u[inside]), t(v[inside]), None), t(wb[inside]))
+        qout = torch.full((int(inside.sum()),), float("nan"), dtype=torch.complex128, device=dev)
+        plan.degrid(t(gcf), t(G), qout)
+        plan.close()
+    finally:
+        ctx.set_option("prepass", 0)
+    for got in (out.cpu().numpy(), pout.cpu().numpy()):
+        assert np.isfinite(got).all() and rel(got, ref) < TOL
+        assert not got[ref == 0].any()
+    q = qout.cpu().numpy()
+    assert np.isfinite(q).all() and rel(q, ref[inside]) < TOL
+
+
 @pytest.mark.parametrize("N,M,W,Q,gh,gw,n,opts", [
     (320, 320, 8, 4, 17, 17, 60000, {}),                # 2 x 2 parts of 9
     (320, 320, 8, 2, 21, 21, 60000, {}),                # 2 x 2 parts of 11
