@@ -83,11 +83,13 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               2 = two levels (the counting sweep leaves 8-byte pre-records, which are LDS-sorted into runs per
  *               coarse bin and then per bin), 3 = one level with global atomics only (no LDS; a measured
  *               baseline), 4 = two levels recomputing from the stream instead of reading pre-records,
- *               5 = two levels with 16-byte instead of 12-byte intermediate records
+ *               5, 6 = two levels with 16-byte / 12-byte instead of 8-byte intermediate records
  *   "aw_cache"  aw gridders: 1 (default) = build each distinct (a1, a2, wbin, yf, xf) kernel once per call and let
  *               the visibilities that share it reuse it; 0 = one kernel per visibility (as the reference evaluates)
  *   "fault_inject"  TEST HOOK: hides the last k slots of the record array from the pre-pass's scatter so that its
  *               bounds checks have something to reject (counted in "errors"; results are then incomplete)
+ *   "rec_bits"  TEST HOOK: pretend the 64-bit record word has this many bits (16..63), so that small calls take the
+ *               path that grids a call in several parts (taken for real above 2^50 slices x visibilities)
  *   ("dbg", the ablation / profiling switch of tuning runs, exists only in the tuning build of the library,
  *   `make -C csrc tuning` -> lib/libgridhip_tuning.so; the shipped library rejects the key)
  * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel

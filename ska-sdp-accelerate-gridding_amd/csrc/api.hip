@@ -110,6 +110,8 @@ int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64
             q.g.P = P;
             q.g.nvis = (int32_t)(n > 0 ? n : 1);  // (nrec stays n * P)
             q.g.nslices = (int32_t)(W * Q * Q * P);
+            set_rec_bits(&q.g);
+            set_div_magic(&q.g);
             const bool want = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && q.nrec / (int64_t)q.g.nbins >= 256);
             q.sorted = want && sorted_plan(ctx, q.g, q.block, &q.nkeys, &q.batch, &q.lds_sorted);
             if (q.sorted) {
@@ -159,6 +161,19 @@ int gridhip_grid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int6
     return GRIDHIP_OK;
 }
 
+// A record is one 64-bit word: 14 bits of footprint origin, the kernel slice, the visibility's index.  A call whose
+// slices x visibilities exceed 2^50 (no realistic one does: 10^8 visibilities leave room for 8 x 10^6 slices) is
+// gridded in several parts - gridding and degridding are both sums / maps over visibilities.  Returns the
+// visibilities per part, 0 when the call fits, < 0 when no part size does.  Option "rec_bits" (test hook) lowers the
+// word's width so that small cases take this path.  (gridhip_last_dropped and "errors" then report the last part's.)
+static int64_t part_size(gridhip_ctx *ctx, const Prep &p)
+{
+    const int limit = ctx->opt.rec_bits >= 16 && ctx->opt.rec_bits < 64 ? (int)ctx->opt.rec_bits : 64;
+    if (p.direct || rec_fits(p.g, limit)) return 0;
+    const int room = limit - 14 - p.g.kb;
+    return room >= 1 ? (int64_t)1 << room : -1;
+}
+
 int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W, int64_t Q,
                           int64_t gh, int64_t gw, const double *gcf, const double *u, const double *v,
                           int64_t uv_stride, const int64_t *wbin, const double *vis)
@@ -172,6 +187,13 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
         p.direct = true;
     else
         GH_CHECK(prepare(ctx, H, Wd, W, Q, gh, gw, n, &p));
+    if (const int64_t part = part_size(ctx, p)) {
+        if (part < 0) return fail(ctx, GRIDHIP_EUNSUPPORTED, "kernel table with too many slices");
+        for (int64_t lo = 0; lo < n; lo += part)
+            GH_CHECK(gridhip_convgrid2_dev(ctx, H, Wd, grid, part < n - lo ? part : n - lo, W, Q, gh, gw, gcf, u + lo * uv_stride,
+                                           v + lo * uv_stride, uv_stride, wbin ? wbin + lo : nullptr, vis + 2 * lo));
+        return GRIDHIP_OK;
+    }
     if (p.direct) {
         mark(ctx, 0);
         mark(ctx, 1);
@@ -181,7 +203,7 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
     }
     // scratch is sized before the timed region begins
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(p.g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(p.nrec > 0 ? p.nrec : 1) * sizeof(VisRec)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(p.nrec > 0 ? p.nrec : 1) * sizeof(RecWord)));
     mark(ctx, 0);
     const double *tk = gcf;
     GH_CHECK(tile_kernels(ctx, p, gcf, &tk));
@@ -216,8 +238,15 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     Prep p;
     GH_CHECK(prepare(ctx, H, Wd, W, Q, gh, gw, n, &p));
     if (p.direct) return fail(ctx, GRIDHIP_EUNSUPPORTED, "degrid2: support %lldx%lld too large for an LDS tile", (long long)gh, (long long)gw);
+    if (const int64_t part = part_size(ctx, p)) {
+        if (part < 0) return fail(ctx, GRIDHIP_EUNSUPPORTED, "kernel table with too many slices");
+        for (int64_t lo = 0; lo < n; lo += part)
+            GH_CHECK(gridhip_degrid2_dev(ctx, H, Wd, grid, part < n - lo ? part : n - lo, W, Q, gh, gw, gcf, u + lo * uv_stride,
+                                         v + lo * uv_stride, uv_stride, wbin ? wbin + lo : nullptr, vis_out + 2 * lo));
+        return GRIDHIP_OK;
+    }
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(p.g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(p.nrec > 0 ? p.nrec : 1) * sizeof(VisRec)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(p.nrec > 0 ? p.nrec : 1) * sizeof(RecWord)));
     mark(ctx, 0);
     // visibilities with no tap inside the grid (or an out-of-range wbin) predict 0: the counting sweep writes those
     // zeros.  Sub-footprints sum a visibility's parts with atomics, so there the whole array starts from zero.

@@ -272,13 +272,16 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
 }
 
 // records come out of the binning pre-pass with kslice = the visibility's index: replace it by its kernel's
-__global__ void aw_relabel_kernel(VisRec *__restrict__ recs, const int32_t *__restrict__ nrec, const int32_t *__restrict__ kid,
-                                  int32_t nvis)
+__global__ void aw_relabel_kernel(Geom g, RecWord *__restrict__ recs, const int32_t *__restrict__ nrec,
+                                  const int32_t *__restrict__ kid, int32_t nvis)
 {
-    const int n = *nrec;
+    const int n = min(*nrec, g.nrec);
+    const RecWord kmask = ((1ull << g.kb) - 1) << g.ob;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int32_t o = recs[i].orig;
-        recs[i].kslice = (uint32_t)o < (uint32_t)nvis ? max(kid[o], 0) : 0;
+        const RecWord w = recs[i];
+        const uint32_t o = (uint32_t)(w & ((1ull << g.ob) - 1));
+        const uint32_t k = o < (uint32_t)nvis ? (uint32_t)max(kid[o], 0) : 0u;
+        recs[i] = (w & ~kmask) | ((RecWord)k << g.ob & kmask);
     }
 }
 
@@ -365,6 +368,7 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         GH_CHECK(rc);
         g.per_vis = 1;
         g.nslices = (int32_t)batch;  // table capacity: a record's kslice is brought below it
+        set_rec_bits(&g);
         p.g = g;
         p.block = block;
         p.lds = lds;
@@ -373,7 +377,7 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         if (p.sorted) p.g.chunk = p.batch;
     }
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(p.g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)batch * sizeof(VisRec)));
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)batch * sizeof(RecWord)));
 
     mark(ctx, 0);
     // ---- antenna-pair kernels
@@ -434,7 +438,7 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         {
             int rb = (int)((m + 255) / 256);
             if (rb > ctx->num_cu * 8) rb = ctx->num_cu * 8;
-            hipLaunchKernelGGL(aw_relabel_kernel, dim3((unsigned)rb), dim3(256), 0, ctx->stream, (VisRec *)ctx->recs.ptr,
+            hipLaunchKernelGGL(aw_relabel_kernel, dim3((unsigned)rb), dim3(256), 0, ctx->stream, p.g, (RecWord *)ctx->recs.ptr,
                                t.bin_start + p.g.nbins, kid, (int32_t)m);
         }
         if (p.sorted)

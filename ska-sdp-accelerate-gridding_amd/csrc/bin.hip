@@ -1,4 +1,4 @@
-// Binning pre-pass: turn the caller's (u, v, wbin) stream into tile-ordered VisRec records so that
+// Binning pre-pass: turn the caller's (u, v, wbin) stream into tile-ordered records (RecWord) so that
 // the tile kernels can accumulate a whole grid tile in LDS.
 //
 //   bin_count   : the ONLY sweep over the caller's stream (24 B per visibility) and the only place the fp64
@@ -9,7 +9,7 @@
 //
 // Small streams (< 2^22 visibilities) then write each record straight to its bin:
 //   bin_offsets : per-work-group histograms -> each work-group's first slot in every bin
-//   bin_scatter : a second sweep over the stream writes each visibility's VisRec into its work-group's range
+//   bin_scatter : a second sweep over the stream writes each visibility's record into its work-group's range
 // A record written straight to its bin is a lone 12-byte store into one of ~10^5 open regions, i.e. one
 // partial-line HBM write per visibility (2.6 ms for 10^8 records against 0.45 ms for the counting sweep), so
 // large streams scatter in two levels, both through an LDS counting sort so that records leave the CU as
@@ -21,8 +21,10 @@
 //                    granularity (one global atomic per chunk and non-empty coarse bin reserves the run's place)
 //   fine_scatter   : equal shares of the temporary array (a chunk spans one or two coarse bins, so few open
 //                    lines per work-group) are sorted by bin the same way and written to the final array
-// Bytes per visibility: 24 read + 8 written (count), 8 + 12 (coarse), 12 + 12 (fine) = 76 B, against 98 B when
-// both scatter levels recomputed from the stream and records were 16 B.  Because the scatter no longer reads the
+// Records are 8-byte words (RecWord, common.h), between the levels as well when the fields fit (FMT 8: the word's
+// spare bits carry the bin's index inside its coarse bin, the coarse bin follows from the record's position).
+// Bytes per visibility: 24 read + 8 written (count), 8 + 8 (coarse), 8 + 8 (fine) = 64 B; 76 B with the 12-byte
+// records of early round 2, 98 B when both scatter levels recomputed from the stream and records were 16 B.  Because the scatter no longer reads the
 // caller's arrays, the count and the scatter cannot disagree (a caller overwriting u, v, wbin during the call
 // changes which records are produced, never where they are written); every record store is bounds-checked
 // against the array all the same and violations are counted (option "errors").
@@ -46,28 +48,51 @@ __device__ __forceinline__ void elem_of(const Geom &g, int64_t e, int64_t *k, in
         *k = e;
         *part = 0;
     } else {
-        const uint32_t kk = (uint32_t)e / (uint32_t)g.P;  // (e < 2^31)
+        const uint32_t kk = udiv_magic((uint32_t)e, g.mP, g.sP);  // (e < 2^31)
         *k = kk;
         *part = (int)((uint32_t)e - kk * (uint32_t)g.P);
     }
 }
 
+// frac_coord of src/Gridding.hs:126-140 for the counting sweep, whose time is its instruction count: the same
+// operations in the same order as frac_coord_dev (common.h) - rounded multiply, rounded add, floor, subtract,
+// multiply, round - but the cell stays a double (`fl`, integer-valued) until it is known to be inside the int32
+// range: frac_coord_dev's (int64) fl and (double) f conversions are a dozen instructions each on this hardware, and
+// for |fl| < 2^31 the second gives back fl exactly, so x - (double)(int64)fl == x - fl bit for bit.
+__device__ __forceinline__ void frac_coord_cell(double nf, double halfnf, double qpxf, double qpxfrac, int32_t qpx, double p,
+                                                double *fl, int32_t *fr)
+{
+#pragma clang fp contract(off)
+    const double pn = p * nf;
+    const double x = halfnf + pn;
+    const double f = floor(x + qpxfrac);
+    const double xd = x - f;
+    const double dd = xd * qpxf;
+    int32_t r = (int32_t)round(dd);
+    r = r < 0 ? 0 : r;
+    r = r > qpx - 1 ? qpx - 1 : r;
+    *fl = f;
+    *fr = r;
+}
+
 __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, int64_t wb, int64_t k, int part)
 {
     BinOut o;
-    int64_t x, y;
+    double xfl, yfl;
     int32_t xf, yf;
-    frac_coord_dev(g.Wd, g.Q, pu, &x, &xf);
-    frac_coord_dev(g.H, g.Q, pv, &y, &yf);
-    int64_t x0 = x - g.fgw / 2, y0 = y - g.fgh / 2;
-    if (g.P > 1) {  // this part's corner of the footprint
-        const int qy = part / g.px, qx = part - qy * g.px;
-        x0 += qx * g.gw;
-        y0 += qy * g.gh;
+    const double qf = (double)g.Q, qfrac = 0.5 / qf;  // (as frac_coord_dev: exact for power-of-two Q, correctly rounded otherwise)
+    frac_coord_cell((double)g.Wd, (double)(g.Wd / 2), qf, qfrac, g.Q, pu, &xfl, &xf);
+    frac_coord_cell((double)g.H, (double)(g.H / 2), qf, qfrac, g.Q, pv, &yfl, &yf);
+    // footprint origin (this part's corner of it), still in doubles: small integers, exact
+    int qy = 0, qx = 0;
+    if (g.P > 1) {
+        qy = (int)udiv_magic((uint32_t)part, g.mPx, g.sPx);
+        qx = part - qy * g.px;
     }
-    // NaN coordinates compare false everywhere below and are dropped by the first test
-    if (!(pu == pu) || !(pv == pv) || x0 <= -(int64_t)g.gw || x0 >= g.Wd || y0 <= -(int64_t)g.gh ||
-        y0 >= g.H) {
+    const double x0 = xfl - (double)(g.fgw / 2 - qx * g.gw), y0 = yfl - (double)(g.fgh / 2 - qy * g.gh);
+    // no tap inside the grid (fixoutofbounds would drop every one).  NaN and infinite coordinates compare false here
+    // and are dropped; everything that passes is far inside the int32 range.
+    if (!(x0 > -(double)g.gw && x0 < (double)g.Wd && y0 > -(double)g.gh && y0 < (double)g.H)) {
         o.bin = -1;
         o.lxy = 0;
         o.kslice = 0;
@@ -81,9 +106,9 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
     }
     const int32_t X = (int32_t)x0 + g.offx, Y = (int32_t)y0 + g.offy;
     // (X, Y >= 0 by construction of offx / offy)
-    const int32_t tx = (int32_t)((uint32_t)X / (uint32_t)g.Tx), ty = (int32_t)((uint32_t)Y / (uint32_t)g.Ty);
+    const int32_t tx = (int32_t)udiv_magic((uint32_t)X, g.mTx, g.sTx), ty = (int32_t)udiv_magic((uint32_t)Y, g.mTy, g.sTy);
     const int32_t lx = X - tx * g.Tx, ly = Y - ty * g.Ty;
-    const int32_t grp = ((int32_t)wb * g.ngroups) / g.W;  // 32-bit: W * ngroups < 2^31
+    const int32_t grp = g.ngroups > 1 ? (int32_t)udiv_magic((uint32_t)((int32_t)wb * g.ngroups), g.mW, g.sW) : 0;  // W * ngroups < 2^31
     o.bin = grp * g.ntiles + ty * g.ntx + tx;
     o.lxy = (ly << 16) | lx;
     o.kslice = g.per_vis ? (int32_t)k : (((int32_t)wb * g.Q + yf) * g.Q + xf) * g.P + part;
@@ -96,12 +121,6 @@ __device__ __forceinline__ BinOut vis_bin(const Geom &g, double pu, double pv, i
 struct PreFmt {
     int bin_bits;  // bits of the bin field (bin_count_kernel: negated = count FROM the pre-records)
 };
-static inline int bits_for(int64_t count)  // bits that hold 0 .. count-1
-{
-    int b = 1;
-    while (((int64_t)1 << b) < count) ++b;
-    return b;
-}
 __device__ __forceinline__ unsigned long long pre_pack(const PreFmt f, const BinOut &b)
 {
     if (b.bin < 0) return ~0ull;
@@ -126,8 +145,11 @@ __device__ __forceinline__ BinOut pre_unpack(const PreFmt f, unsigned long long 
 }
 
 // ---- records between the two scatter levels -------------------------------------------------------
-// The final record plus its bin.  T12: 12 bytes, the bin in the 18 bits of lxy that lx and ly (7 bits each, tiles
-// are at most 128 cells) leave free - bins < 2^18; otherwise 16 bytes with the bin in a fourth word.
+// FMT 8: the final 8-byte word with, in the bits above its fields (from bit ob + kb + 14), the bin's index inside its
+// coarse bin (bin & (2^shift - 1)); which coarse bin follows from where the record lies in the coarse-ordered array.
+// Level 2 keeps a 10-bit sort key in the same place while a chunk is in LDS, hence the condition ob + kb <= 40.
+// Otherwise the unpacked record plus its bin - T12: 12 bytes, the bin in the 18 bits of lxy that lx and ly (7 bits
+// each, tiles are at most 128 cells) leave free - bins < 2^18; or 16 bytes with the bin in a fourth word.
 constexpr int TMP12_MAX_BINS = 1 << 18;
 template <bool T12>
 struct TmpRec;
@@ -144,7 +166,7 @@ struct TmpRec<true> {
     {
         return (int32_t)(((uint32_t)lxy >> 7) & 0x1ff) | (int32_t)(((uint32_t)lxy >> 23) << 9);
     }
-    __device__ __forceinline__ VisRec final_rec() const { return VisRec{lxy & 0x007f007f, kslice, orig}; }
+    __device__ __forceinline__ RecWord final_rec(const Geom &g) const { return rec_pack(g, lxy & 0x007f007f, kslice, orig); }
 };
 template <>
 struct TmpRec<false> {
@@ -157,7 +179,7 @@ struct TmpRec<false> {
         b = bin;
     }
     __device__ __forceinline__ int32_t bin() const { return b; }
-    __device__ __forceinline__ VisRec final_rec() const { return VisRec{lxy, kslice, orig}; }
+    __device__ __forceinline__ RecWord final_rec(const Geom &g) const { return rec_pack(g, lxy, kslice, orig); }
 };
 static_assert(sizeof(TmpRec<true>) == 12 && sizeof(TmpRec<false>) == 16, "record sizes");
 
@@ -363,7 +385,7 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
                                                            const int32_t *__restrict__ bin_start,
                                                            int32_t *__restrict__ cursor,
                                                            const int32_t *__restrict__ block_hist,
-                                                           VisRec *__restrict__ recs, int bin_lo, int bin_hi,
+                                                           RecWord *__restrict__ recs, int bin_lo, int bin_hi,
                                                            int32_t cap, int32_t *__restrict__ scalars)
 {
     extern __shared__ int32_t hist[];
@@ -392,7 +414,7 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
             ++bad;
             continue;
         }
-        recs[slot] = VisRec{b.lxy, b.kslice, (int32_t)k};
+        recs[slot] = rec_pack(g, b.lxy, b.kslice, (int32_t)k);
     }
     if (bad) atomicAdd(&scalars[2], bad);
 }
@@ -402,6 +424,12 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
 // reserve(e, count, base) is called for every non-empty entry and its result kept in res[] (one slot per entry of
 // the thread) - the caller publishes the results later, so that a returning global atomic issued in `reserve` is not
 // waited for here; wtot[16] receives the total.
+// Barrier between the LDS phases of the scatter kernels.  __syncthreads() also waits for every outstanding global
+// access of the wave (s_waitcnt vmcnt(0): on this hardware stores and loads share that counter), which would expose the
+// latency of the next chunk's prefetch and of the previous chunk's stores at every phase boundary.  The phases only
+// hand LDS data to each other; registers fed by global loads and returning atomics are waited for where they are used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NT, typename F>
 __device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *wtot, int (&res)[1024 / NT], F &&reserve)
 {
@@ -421,7 +449,7 @@ __device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *w
         if (lane >= off) incl += t;
     }
     if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
+    lds_barrier();
     int base = incl - sum;
     for (int w = 0; w < wave; ++w) base += wtot[w];
 #pragma unroll
@@ -451,25 +479,31 @@ __device__ __forceinline__ void publish_entries(int32_t *gbase, int nent, const 
 // Level 1.  tmp is laid out like the final record array at coarse granularity: coarse bin c owns
 // [bin_start[c << shift], bin_start[min((c + 1) << shift, nbins)]).  Each chunk reserves, per coarse bin, a
 // contiguous range there (one global atomic per chunk and non-empty coarse bin) and writes its records as
-// runs; the record carries its bin for level 2.
+// runs; the record carries its bin for level 2 (FMT 8: the bin's low `shift` bits).
 // FROM_PRE: the chunk is read from the counting sweep's pre-records; otherwise it is recomputed from the stream.
-template <int NT, int CHUNK, bool FROM_PRE, bool T12>
+template <int NT, int CHUNK, bool FROM_PRE, int FMT>
 __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n, const double *__restrict__ u,
                                                                const double *__restrict__ v, int64_t stride,
                                                                const int64_t *__restrict__ wbin,
                                                                const int32_t *__restrict__ bin_start,
                                                                int32_t *__restrict__ ccur, int shift, int ncoarse,
-                                                               TmpRec<T12> *__restrict__ tmp,
+                                                               void *__restrict__ tmp_,
                                                                const unsigned long long *__restrict__ pre, PreFmt pf,
                                                                int32_t cap, int32_t *__restrict__ scalars)
 {
+    using Tmp = TmpRec<FMT != 16>;
+    constexpr int RW = FMT == 8 ? 2 : (int)sizeof(Tmp) / 4;  // 32-bit words per staged record
     extern __shared__ int32_t smem[];
-    TmpRec<T12> *sorted = reinterpret_cast<TmpRec<T12> *>(smem);  // [CHUNK]
-    int32_t *hist = smem + CHUNK * (sizeof(TmpRec<T12>) / 4);     // [ncoarse]: count, then the coarse bin's first slot in `sorted`
+    Tmp *sorted = reinterpret_cast<Tmp *>(smem);              // [CHUNK] (FMT 12, 16)
+    RecWord *sorted8 = reinterpret_cast<RecWord *>(smem);     // [CHUNK] (FMT 8)
+    uint16_t *scoarse = reinterpret_cast<uint16_t *>(smem + CHUNK * RW);  // [CHUNK] (FMT 8): coarse bin of sorted8[i]
+    int32_t *hist = smem + CHUNK * RW + (FMT == 8 ? CHUNK / 2 : 0);  // [ncoarse]: count, then the coarse bin's first slot in `sorted`
     int32_t *gbase = hist + ncoarse;                              // [ncoarse]: tmp position of sorted[0] if it were in this bin
     int32_t *wtot = gbase + ncoarse;                              // [16] per-wave totals of the scan, [16] = chunk total
     const int tid = threadIdx.x;
     constexpr int PER = CHUNK / NT;
+    const int fbit = g.ob + g.kb + 14;                            // (FMT 8) where the fine index sits in the word
+    const RecWord fmask = (1ull << shift) - 1;
     int64_t lo, hi;
     block_range(n, &lo, &hi);
     int bad = 0;
@@ -485,7 +519,7 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
     }
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         for (int i = tid; i < ncoarse; i += NT) hist[i] = 0;
-        __syncthreads();
+        lds_barrier();
         BinOut b[PER];
         int rank[PER];
 #pragma unroll
@@ -507,37 +541,53 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
 #pragma unroll
         for (int q = 0; q < PER; ++q)
             rank[q] = b[q].bin >= 0 ? atomicAdd(&hist[b[q].bin >> shift], 1) : 0;
-        __syncthreads();
+        lds_barrier();
         // exclusive scan of the counts and the global reservations; the returning atomics travel while the chunk
         // is sorted in LDS (which needs the local offsets only)
         int res[1024 / NT];
         scan_entries<NT>(hist, ncoarse, wtot, res, [&](int e, int c, int base) {
             return bin_start[e << shift] + atomicAdd(&ccur[e], c) - base;
         });
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             if (b[q].bin < 0) continue;
-            TmpRec<T12> r;
             int64_t kv;
             int part;
             elem_of(g, c0 + q * NT + tid, &kv, &part);
-            r.set(b[q].lxy, b[q].kslice, (int32_t)kv, b[q].bin);
-            sorted[hist[b[q].bin >> shift] + rank[q]] = r;
+            const int pos = hist[b[q].bin >> shift] + rank[q];
+            if (FMT == 8) {
+                sorted8[pos] = rec_pack(g, b[q].lxy, b[q].kslice, (int32_t)kv) | ((RecWord)(uint32_t)b[q].bin & fmask) << fbit;
+                scoarse[pos] = (uint16_t)(b[q].bin >> shift);
+            } else {
+                Tmp r;
+                r.set(b[q].lxy, b[q].kslice, (int32_t)kv, b[q].bin);
+                sorted[pos] = r;
+            }
         }
         publish_entries<NT>(gbase, ncoarse, res);
-        __syncthreads();
+        lds_barrier();
         const int total = wtot[16];
         for (int i = tid; i < total; i += NT) {
-            const TmpRec<T12> r = sorted[i];
-            const int slot = gbase[r.bin() >> shift] + i;  // neighbouring lanes: neighbouring slots
-            if ((uint32_t)slot >= (uint32_t)cap) {
-                ++bad;
-                continue;
+            // neighbouring lanes: neighbouring slots
+            if (FMT == 8) {
+                const int slot = gbase[scoarse[i]] + i;
+                if ((uint32_t)slot >= (uint32_t)cap) {
+                    ++bad;
+                    continue;
+                }
+                static_cast<RecWord *>(tmp_)[slot] = sorted8[i];
+            } else {
+                const Tmp r = sorted[i];
+                const int slot = gbase[r.bin() >> shift] + i;
+                if ((uint32_t)slot >= (uint32_t)cap) {
+                    ++bad;
+                    continue;
+                }
+                static_cast<Tmp *>(tmp_)[slot] = r;
             }
-            tmp[slot] = r;
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (bad) atomicAdd(&scalars[2], bad);
 }
@@ -547,50 +597,118 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
 // coarse bins, i.e. at most a few hundred bins.  The chunk is counting-sorted by bin in LDS exactly as level 1 sorts
 // by coarse bin, each bin's range is reserved with one global atomic, and the records leave as runs.  A chunk that
 // spans more than 1024 bins (very sparse regions) falls back to one global atomic per record.
-template <int NT, int CHUNK, bool T12>
+// What one staged record is, per format: its sort key (bin - k0) and the final word it becomes.
+template <int FMT>
+struct FineRec;
+template <>
+struct FineRec<8> {
+    RecWord w;  // (in LDS: the 10-bit key where the fine index was)
+};
+template <>
+struct FineRec<12> {
+    TmpRec<true> r;
+};
+template <>
+struct FineRec<16> {
+    TmpRec<false> r;
+};
+
+template <int NT, int CHUNK, int FMT>
 __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32_t *__restrict__ bin_start,
-                                                             int32_t *__restrict__ cursor, int shift,
-                                                             const TmpRec<T12> *__restrict__ tmp,
-                                                             VisRec *__restrict__ out, int32_t cap,
+                                                             int32_t *__restrict__ cursor, int shift, int ncoarse,
+                                                             const void *__restrict__ tmp_,
+                                                             RecWord *__restrict__ out, int32_t cap,
                                                              int32_t *__restrict__ scalars)
 {
+    using Rec = FineRec<FMT>;
+    constexpr int RW = (int)sizeof(Rec) / 4;
     extern __shared__ int32_t smem[];
-    TmpRec<T12> *sorted = reinterpret_cast<TmpRec<T12> *>(smem);  // [CHUNK]
-    int32_t *hist = smem + CHUNK * (sizeof(TmpRec<T12>) / 4);     // [1024]
-    int32_t *gbase = hist + 1024;                                 // [1024]
-    int32_t *wtot = gbase + 1024;                                 // [17]
+    Rec *sorted = reinterpret_cast<Rec *>(smem);  // [CHUNK]
+    int32_t *hist = smem + CHUNK * RW;            // [1024]
+    int32_t *gbase = hist + 1024;                 // [1024]
+    int32_t *wtot = gbase + 1024;                 // [32]: [0..16] scan, [24], [25] the chunk's first / last bin or coarse bin
+    int32_t *cend = wtot + 32;                    // (FMT 8) [ncoarse]: where each coarse bin ends in tmp
+    const Rec *tmp = static_cast<const Rec *>(tmp_);
     const int tid = threadIdx.x;
     constexpr int PER = CHUNK / NT;
+    const int fbit = g.ob + g.kb + 14;
+    const RecWord lowmask = (1ull << fbit) - 1, fmask = (1ull << shift) - 1;
     int64_t ntot = bin_start[g.nbins];
     if (ntot > cap) ntot = cap;  // (level 1 has written nothing beyond `cap`)
     int64_t per = (ntot + gridDim.x - 1) / gridDim.x;
     per = (per + CHUNK - 1) / CHUNK * CHUNK;
     const int64_t lo = min((int64_t)blockIdx.x * per, ntot), hi = min(lo + per, ntot);
     int bad = 0;
-    // (the next chunk's records travel while this chunk goes through its LDS phases, as in level 1)
-    TmpRec<T12> nxt[PER];
-    if (lo < hi) {
+    if (FMT == 8) {
+        for (int t = tid; t < ncoarse; t += NT) cend[t] = bin_start[min((t + 1) << shift, g.nbins)];
+        lds_barrier();
+    }
+    // (FMT 8) the coarse bin position i of tmp lies in, searching upwards from c (positions come in rising order)
+    auto coarse_at = [&](int64_t i, int c) {
+        while (c < ncoarse - 1 && i >= cend[c]) ++c;
+        return c;
+    };
+    auto bin_of = [&](const Rec &x, int64_t i, int &c) -> int {
+        if constexpr (FMT == 8) {
+            c = coarse_at(i, c);
+            return (c << shift) | (int)((x.w >> fbit) & fmask);
+        } else
+            return x.r.bin();
+    };
+    auto final_of = [&](const Rec &x) -> RecWord {
+        if constexpr (FMT == 8)
+            return x.w & lowmask;
+        else
+            return x.r.final_rec(g);
+    };
+    // The next chunk's records travel while this chunk goes through its LDS phases, as in level 1.  (Two work-groups
+    // per CU instead - 8-byte records leave the LDS for it, at 64 registers per thread and without this prefetch -
+    // measured slower: 1.63 against 1.55 ms for the whole pre-pass.)
+    constexpr bool PREF = true;
+    Rec nxt[PER];
+    if (PREF && lo < hi) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(lo + q * NT + tid, hi - 1)];  // (unconditional: indices clamped)
     }
     for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
         const int64_t c1 = min(c0 + CHUNK, hi);
-        // the chunk's first and last record are in two threads' prefetch registers: hand them round through LDS
+        if (!PREF) {
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int64_t i = c0 + q * NT + tid;
-            if (i == c0) wtot[24] = nxt[q].bin();
-            if (i == c1 - 1) wtot[25] = nxt[q].bin();
+            for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + q * NT + tid, hi - 1)];
         }
-        __syncthreads();
-        int b_first = wtot[24], b_last = wtot[25];
-        b_first = min(max(b_first, 0), g.nbins - 1);
-        b_last = min(max(b_last, b_first), g.nbins - 1);
+        int b_first, b_last, cfirst = 0;
+        if (FMT == 8) {
+            // the coarse bins of the chunk's first and last position: exactly one (non-empty) coarse bin holds each
+            for (int t = tid; t < ncoarse; t += NT) {
+                const int64_t cs = t ? cend[t - 1] : 0, ce = cend[t];
+                if (cs <= c0 && c0 < ce) wtot[24] = t;
+                if (cs <= c1 - 1 && c1 - 1 < ce) wtot[25] = t;
+            }
+            lds_barrier();
+            cfirst = min(max(wtot[24], 0), ncoarse - 1);
+            const int clast = min(max(wtot[25], cfirst), ncoarse - 1);
+            b_first = cfirst << shift;
+            b_last = min(((clast + 1) << shift) - 1, g.nbins - 1);
+        } else {
+            // the chunk's first and last record are in two threads' prefetch registers: hand them round through LDS
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int64_t i = c0 + q * NT + tid;
+                int c = 0;
+                if (i == c0) wtot[24] = bin_of(nxt[q], i, c);
+                if (i == c1 - 1) wtot[25] = bin_of(nxt[q], i, c);
+            }
+            lds_barrier();
+            b_first = wtot[24], b_last = wtot[25];
+            b_first = min(max(b_first, 0), g.nbins - 1);
+            b_last = min(max(b_last, b_first), g.nbins - 1);
+        }
         const int k0 = (b_first >> shift) << shift, span = (((b_last >> shift) + 1) << shift) - k0;  // bins k0 .. k0 + span
         if (span > 1024) {  // rare: one global atomic per record
+            int c = cfirst;
             for (int64_t i = c0 + tid; i < c1; i += NT) {
-                const TmpRec<T12> r = tmp[i];
-                const int k = r.bin();
+                const Rec r = tmp[i];
+                const int k = bin_of(r, i, c);
                 if ((uint32_t)k >= (uint32_t)g.nbins) {
                     ++bad;
                     continue;
@@ -600,82 +718,97 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
                     ++bad;
                     continue;
                 }
-                out[slot] = r.final_rec();
+                out[slot] = final_of(r);
             }
+            if (PREF) {
 #pragma unroll
-            for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
+                for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
+            }
+            lds_barrier();  // (wtot[24], [25] are rewritten by the next chunk)
             continue;
         }
         for (int i = tid; i < span; i += NT) hist[i] = 0;
-        __syncthreads();
-        TmpRec<T12> r[PER];
+        lds_barrier();
+        Rec r[PER];
         int key[PER], rank[PER];
+        int c = cfirst;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int64_t i = c0 + q * NT + tid;
             key[q] = -1;
             if (i < c1) {
                 r[q] = nxt[q];
-                key[q] = r[q].bin() - k0;
+                key[q] = bin_of(r[q], i, c) - k0;
                 if ((uint32_t)key[q] >= (uint32_t)span || k0 + key[q] >= g.nbins) {  // tmp not ordered (cannot happen)
                     key[q] = -1;
                     ++bad;
                 }
             }
         }
+        if (PREF) {
 #pragma unroll
-        for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
+            for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
+        }
 #pragma unroll
         for (int q = 0; q < PER; ++q) rank[q] = key[q] >= 0 ? atomicAdd(&hist[key[q]], 1) : 0;
-        __syncthreads();
+        lds_barrier();
         int res[1024 / NT];
-        scan_entries<NT>(hist, span, wtot, res, [&](int e, int c, int base) {
-            return bin_start[k0 + e] + atomicAdd(&cursor[k0 + e], c) - base;
+        scan_entries<NT>(hist, span, wtot, res, [&](int e, int c_, int base) {
+            return bin_start[k0 + e] + atomicAdd(&cursor[k0 + e], c_) - base;
         });
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
-        for (int q = 0; q < PER; ++q)
-            if (key[q] >= 0) sorted[hist[key[q]] + rank[q]] = r[q];
+        for (int q = 0; q < PER; ++q) {
+            if (key[q] < 0) continue;
+            if constexpr (FMT == 8) r[q].w = (r[q].w & lowmask) | (RecWord)key[q] << fbit;  // the key replaces the fine index
+            sorted[hist[key[q]] + rank[q]] = r[q];
+        }
         publish_entries<NT>(gbase, span, res);
-        __syncthreads();
+        lds_barrier();
         const int total = wtot[16];
         for (int i = tid; i < total; i += NT) {
-            const TmpRec<T12> x = sorted[i];
-            const int slot = gbase[x.bin() - k0] + i;
+            const Rec x = sorted[i];
+            int kx;
+            if constexpr (FMT == 8)
+                kx = (int)(x.w >> fbit);
+            else
+                kx = x.r.bin() - k0;
+            const int slot = gbase[kx] + i;
             if ((uint32_t)slot >= (uint32_t)cap) {
                 ++bad;
                 continue;
             }
-            out[slot] = x.final_rec();
+            out[slot] = final_of(x);
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (bad) atomicAdd(&scalars[2], bad);
 }
 
 // NT threads take chunks of CHUNK records: <1024, 8192> is one work-group per CU (LDS), <512, 4096> two, so that one
 // drains its stores and waits for its reservations while the other sorts.
-template <bool FROM_PRE, bool T12, int NT, int CHUNK>
+template <bool FROM_PRE, int FMT, int NT, int CHUNK>
 static int launch_two_level(gridhip_ctx *ctx, const Geom &g, const Tables &t, int64_t n, const double *u, const double *v,
                             int64_t uv_stride, const int64_t *wbin, int shift, int ncoarse, int cblocks,
                             const unsigned long long *pre, PreFmt pf, int32_t cap)
 {
-    const size_t coarse_lds = (size_t)CHUNK * sizeof(TmpRec<T12>) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
-    const size_t fine_lds = (size_t)CHUNK * sizeof(TmpRec<T12>) + (size_t)(2 * 1024 + 32) * sizeof(int32_t);
-    auto coarse = coarse_scatter_kernel<NT, CHUNK, FROM_PRE, T12>;
-    auto fine = fine_scatter_kernel<NT, CHUNK, T12>;
-    const uint32_t bit = 2u << ((FROM_PRE ? 1 : 0) + (T12 ? 2 : 0) + (NT == 512 ? 4 : 0));
+    const size_t rec_bytes = FMT;
+    const size_t coarse_lds = (size_t)CHUNK * (rec_bytes + (FMT == 8 ? 2 : 0)) + (size_t)(2 * ncoarse + 32) * sizeof(int32_t);
+    const size_t fine_lds = (size_t)CHUNK * rec_bytes + (size_t)(2 * 1024 + 32 + (FMT == 8 ? ncoarse : 0)) * sizeof(int32_t);
+    auto coarse = coarse_scatter_kernel<NT, CHUNK, FROM_PRE, FMT>;
+    auto fine = fine_scatter_kernel<NT, CHUNK, FMT>;
+    const uint32_t bit = 2u << ((FROM_PRE ? 1 : 0) + (FMT == 12 ? 2 : FMT == 8 ? 8 : 0) + (NT == 512 ? 4 : 0));
     if (!(ctx->attr_mask & bit)) {
         GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)coarse, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
         GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)fine, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
         ctx->attr_mask |= bit;
     }
     int32_t *ccur = (int32_t *)ctx->blockhist.ptr;
-    TmpRec<T12> *tmp = (TmpRec<T12> *)ctx->recs_tmp.ptr;
+    void *tmp = ctx->recs_tmp.ptr;
     hipLaunchKernelGGL(coarse, dim3(cblocks), dim3(NT), coarse_lds, ctx->stream, g, n, u, v, uv_stride, wbin, t.bin_start,
                        ccur, shift, ncoarse, tmp, pre, pf, cap, t.scalars);
-    hipLaunchKernelGGL(fine, dim3(cblocks), dim3(NT), fine_lds, ctx->stream, g, t.bin_start, t.cursor, shift,
-                       (const TmpRec<T12> *)tmp, (VisRec *)ctx->recs.ptr, cap, t.scalars);
+    hipLaunchKernelGGL(fine, dim3(cblocks), dim3(NT), fine_lds, ctx->stream, g, t.bin_start, t.cursor, shift, ncoarse,
+                       (const void *)tmp, (RecWord *)ctx->recs.ptr, cap, t.scalars);
     return GRIDHIP_OK;
 }
 
@@ -683,7 +816,8 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
                int64_t uv_stride, const int64_t *wbin, double2 *zero_out)
 {
     GH_CHECK(ws_reserve(ctx, ctx->tables, tables_bytes(g)));
-    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(VisRec)));
+    if (!rec_fits(g)) return fail(ctx, GRIDHIP_EUNSUPPORTED, "record fields need %d bits", g.ob + g.kb + 14);  // (api.hip cuts such calls)
+    GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(n > 0 ? n : 1) * sizeof(RecWord)));
     Tables t = tables_of(ctx, g);
     int32_t *block_hist = nullptr;
     // scalars: [0] = dropped (wbin out of range), [2] = errors
@@ -731,10 +865,12 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
     if (shift > 10) shift = 10;  // (level 2 sorts at most 1024 bins per coarse bin in LDS)
     while (((g.nbins + (1 << shift) - 1) >> shift) > 1024) ++shift;
     const int ncoarse = (g.nbins + (1 << shift) - 1) >> shift;
-    const bool two_level = lds_hist && (p == 2 || p == 4 || p == 5 || (p == 0 && n >= ((int64_t)1 << 22)));
+    const bool two_level = lds_hist && (p == 2 || p == 4 || p == 5 || p == 6 || (p == 0 && n >= ((int64_t)1 << 22)));
     if (two_level) {
-        const bool t12 = g.nbins <= TMP12_MAX_BINS && p != 5;  // (tile sides <= 128: lx, ly take 7 bits each)
-        GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * (t12 ? 12 : 16)));
+        // record format between the levels: 8 bytes when the fields leave 10 bits for level 2's sort key, else 12
+        // (bins < 2^18), else 16 (options prepass = 5, 6: 16 and 12 bytes regardless, for comparison)
+        const int fmt = (p != 5 && p != 6 && g.ob + g.kb <= 40) ? 8 : (g.nbins <= TMP12_MAX_BINS && p != 5) ? 12 : 16;
+        GH_CHECK(ws_reserve(ctx, ctx->recs_tmp, (size_t)(n > 0 ? n : 1) * fmt));
         GH_CHECK(ws_reserve(ctx, ctx->blockhist, (size_t)ncoarse * sizeof(int32_t)));  // coarse cursors
         launch_clear(ctx, t.bin_count, g.nbins, t.scalars, 3, (int32_t *)ctx->blockhist.ptr, ncoarse);
         // chunk size: 8192 records, one work-group per CU (option scatter_chunk = 4096: two per CU; measured no faster)
@@ -771,14 +907,18 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
                                                         pf, cap)                                                          \
                  : launch_two_level<P_, T_, 1024, 8192>(ctx, g, t, n, u, v, uv_stride, wbin, shift, ncoarse, cblocks,   \
                                                          pre, pf, cap))
-        if (use_pre && t12)
-            GH_CHECK(GH_TWO(true, true));
+        if (use_pre && fmt == 8)
+            GH_CHECK(GH_TWO(true, 8));
+        else if (use_pre && fmt == 12)
+            GH_CHECK(GH_TWO(true, 12));
         else if (use_pre)
-            GH_CHECK(GH_TWO(true, false));
-        else if (t12)
-            GH_CHECK(GH_TWO(false, true));
+            GH_CHECK(GH_TWO(true, 16));
+        else if (fmt == 8)
+            GH_CHECK(GH_TWO(false, 8));
+        else if (fmt == 12)
+            GH_CHECK(GH_TWO(false, 12));
         else
-            GH_CHECK(GH_TWO(false, false));
+            GH_CHECK(GH_TWO(false, 16));
 #undef GH_TWO
         GH_CHECK_HIP(ctx, hipGetLastError());
         return GRIDHIP_OK;
@@ -807,12 +947,12 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
         for (int wdw = 0; wdw < windows; ++wdw) {
             const int b_lo = wdw * win, b_hi = b_lo + win < g.nbins ? b_lo + win : g.nbins;
             hipLaunchKernelGGL(bin_scatter_kernel<true>, dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n,
-                               u, v, uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr,
+                               u, v, uv_stride, wbin, t.bin_start, t.cursor, block_hist, (RecWord *)ctx->recs.ptr,
                                b_lo, b_hi, cap, t.scalars);
         }
     } else
         hipLaunchKernelGGL(bin_scatter_kernel<false>, dim3(blocks), dim3(threads), 0, ctx->stream, g, n, u, v,
-                           uv_stride, wbin, t.bin_start, t.cursor, block_hist, (VisRec *)ctx->recs.ptr, 0, g.nbins,
+                           uv_stride, wbin, t.bin_start, t.cursor, block_hist, (RecWord *)ctx->recs.ptr, 0, g.nbins,
                            cap, t.scalars);
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;

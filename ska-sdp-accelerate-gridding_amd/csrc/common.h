@@ -11,15 +11,18 @@
 namespace gridhip {
 
 // One visibility after the binning pre-pass: where its footprint starts inside the tile, which
-// kernel slice it uses and where its value lives in the caller's array.  12 B: one dwordx3 access.
+// kernel slice it uses and where its value lives in the caller's array.
 // Records do not depend on the visibility values: the image and PSF passes of do_imaging
 // (src/Gridding.hs:538,541) can share one binning.
+// In memory a record is one 64-bit word (RecWord): orig | kslice << ob | lx << (ob + kb) | ly << (ob + kb + 7), with
+// the field widths ob, kb taken from the call's sizes (Geom; 27 + 13 + 14 = 54 bits in the headline case).  VisRec is
+// the unpacked form the kernels work with.
 struct VisRec {
     int32_t lxy;     // ly0 << 16 | lx0 : footprint origin relative to the tile's LDS region
     int32_t kslice;  // (wbin*Q + yf)*Q + xf : which [gh][gw] kernel slice
     int32_t orig;    // index in the caller's arrays (vis is gathered from / degrid writes there)
 };
-static_assert(sizeof(VisRec) == 12, "VisRec must be 12 bytes");
+typedef unsigned long long RecWord;
 
 // Geometry of one gridding call, shared by host and device code.
 struct Geom {
@@ -45,10 +48,65 @@ struct Geom {
     // (kslice * P + part), and the kernels see nothing but more visibilities of a small square support.
     // fgh x fgw is the kernel the caller passed (the footprint origin is x - fgw / 2, y - fgh / 2).
     int32_t fgh, fgw, px, py, P;
+    int32_t ob, kb;       // record layout: bits of the orig and kslice fields (set_rec_bits)
+    // division by Tx, Ty, W, P, px in the counting sweep without a divide: x / d == umulhi(x, m) >> s for 0 <= x < 2^31
+    // (set_div_magic; the sweep is bound by its instruction count, and a 32-bit divide is ~30 instructions)
+    uint32_t mTx, mTy, mW, mP, mPx;
+    int32_t sTx, sTy, sW, sP, sPx;
 };
 
+// m, s with x / d == (x * m) >> (32 + s) for every 0 <= x < 2^31 (round-up method: m = ceil(2^(31 + l) / d),
+// l = ceil(log2 d), which fits 32 bits because d > 2^(l - 1)); d = 1 is s = -1 (the quotient is x)
+static inline void div_magic(int64_t d, uint32_t *m, int32_t *s)
+{
+    if (d <= 1) {
+        *m = 0;
+        *s = -1;
+        return;
+    }
+    int l = 0;
+    while (((int64_t)1 << l) < d) ++l;
+    const unsigned __int128 num = (unsigned __int128)1 << (31 + l);
+    *m = (uint32_t)((num + (unsigned __int128)d - 1) / (unsigned __int128)d);
+    *s = l - 1;
+}
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t m, int32_t s)
+{
+    return s < 0 ? x : __umulhi(x, m) >> s;
+}
+static inline void set_div_magic(Geom *g)
+{
+    div_magic(g->Tx, &g->mTx, &g->sTx);
+    div_magic(g->Ty, &g->mTy, &g->sTy);
+    div_magic(g->W, &g->mW, &g->sW);
+    div_magic(g->P, &g->mP, &g->sP);
+    div_magic(g->px, &g->mPx, &g->sPx);
+}
+
+static inline int bits_for(int64_t count)  // bits that hold 0 .. count-1
+{
+    int b = 1;
+    while (((int64_t)1 << b) < count) ++b;
+    return b;
+}
+// field widths of the packed record from the call's sizes; a call whose fields do not fit 64 bits is cut into
+// several (api.hip: more than 2^50 / slices visibilities)
+static inline void set_rec_bits(Geom *g)
+{
+    g->ob = bits_for(g->nvis);
+    int64_t ks = g->nslices;
+    if (g->per_vis && g->nvis > ks) ks = g->nvis;  // (aw gridders: kslice starts as the visibility's index)
+    g->kb = bits_for(ks);
+}
+static inline bool rec_fits(const Geom &g, int limit = 64) { return g.ob + g.kb + 14 <= limit; }
+__host__ __device__ __forceinline__ RecWord rec_pack(const Geom &g, int32_t lxy, int32_t kslice, int32_t orig)
+{
+    return (RecWord)(uint32_t)orig | (RecWord)(uint32_t)kslice << g.ob | (RecWord)((uint32_t)lxy & 0x7f) << (g.ob + g.kb) |
+           (RecWord)(((uint32_t)lxy >> 16) & 0x7f) << (g.ob + g.kb + 7);
+}
+
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0, rec_bits = 0;
 };
 
 struct Workspace {
@@ -65,7 +123,7 @@ struct gridhip_ctx {
     std::string err;
     gridhip::Options opt;
     // device scratch, grown on demand (never inside a timed/captured region after warm-up)
-    gridhip::Workspace recs;    // VisRec[n]
+    gridhip::Workspace recs;    // RecWord[n]
     gridhip::Workspace tables;  // bin_count / bin_start / work_start / cursors / scalars
     gridhip::Workspace stage;   // staging for the host-pointer entry points
     gridhip::Workspace sorted;  // sorted-list scratch of the tap-reusing tile kernel (tile_sorted.hip)

@@ -93,6 +93,8 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->fgh = (int32_t)gh;
     g->fgw = (int32_t)gw;
     g->px = g->py = g->P = 1;
+    g->per_vis = 0;
+    set_rec_bits(g);
 
     const size_t lds_cap = (size_t)ctx->max_lds - 1024;
     // one plane (re or im) of the tap-reusing kernel's tile must fit below the fixed re / im distance (tile_sorted.hip)
@@ -166,9 +168,11 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
         if (ng == 8 && (int64_t)g->ntiles * 8 > 4 * cap) ng = 4;
     }
     if (ng > W) ng = (int)W;
+    if (W * ng >= ((int64_t)1 << 31)) ng = 1;  // (the group of a plane is computed in 32 bits)
     if (ng < 1 || ng > 16) return fail(ctx, GRIDHIP_EINVAL, "wgroups must be in 1..16");
     g->ngroups = ng;
     g->nbins = ng * g->ntiles;
+    set_div_magic(g);
 
     int chunk = (int)ctx->opt.chunk;
     if (chunk == 0) chunk = 8192;
@@ -329,6 +333,7 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "coarse_shift")) return &ctx->opt.coarse_shift;
     if (!strcmp(key, "scatter_chunk")) return &ctx->opt.scatter_chunk;
     if (!strcmp(key, "count_unroll")) return &ctx->opt.count_unroll;
+    if (!strcmp(key, "rec_bits")) return &ctx->opt.rec_bits;
     return nullptr;
 }
 

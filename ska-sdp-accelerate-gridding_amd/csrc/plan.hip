@@ -55,6 +55,7 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
     p->n = n;
     int rc = prepare(ctx, H, Wd, W, Q, gh, gw, n, &p->p);
     if (rc == GRIDHIP_OK && p->p.direct) rc = fail(ctx, GRIDHIP_EUNSUPPORTED, "plan: support too large for an LDS tile");
+    if (rc == GRIDHIP_OK && !rec_fits(p->p.g)) rc = fail(ctx, GRIDHIP_EUNSUPPORTED, "plan: slices x visibilities above 2^50");
     if (rc != GRIDHIP_OK) {
         delete p;
         return rc;
@@ -62,7 +63,7 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
     {
         Lend lend(p);
         rc = ws_reserve(ctx, ctx->tables, tables_bytes(p->p.g));
-        if (rc == GRIDHIP_OK) rc = ws_reserve(ctx, ctx->recs, (size_t)(p->p.nrec > 0 ? p->p.nrec : 1) * sizeof(VisRec));
+        if (rc == GRIDHIP_OK) rc = ws_reserve(ctx, ctx->recs, (size_t)(p->p.nrec > 0 ? p->p.nrec : 1) * sizeof(RecWord));
         if (rc == GRIDHIP_OK) rc = launch_bin(ctx, p->p.g, p->p.nrec, u, v, uv_stride, wbin);
         if (rc == GRIDHIP_OK && p->p.g.P == 1 && n > 0) {
             // how many visibilities found a bin: when all did, degrid passes skip clearing their output

@@ -42,23 +42,24 @@ __device__ __forceinline__ bool find_work(const Geom &g, const int32_t *__restri
     return find_work_at(g, bin_start, work_start, blockIdx.x % g.ngroups, blockIdx.x / g.ngroups, w);
 }
 
-// All lanes of the wave read the same 12 bytes (one broadcast transaction), or consecutive records (coalesced).
+// All lanes of the wave read the same 8 bytes (one broadcast transaction), or consecutive records (coalesced).
 // Vector loads on purpose: scalar loads share the lgkmcnt counter with the LDS atomics and would make every
 // record fetch wait for the wave's outstanding ds_add_f64s.
 // Nothing read from a record becomes an address before it has been brought into range: a record slot the pre-pass
 // never wrote (only possible when the caller's arrays change between its sweeps) holds stale bytes, and those may
 // cost a wrong sum but never a wild access.
-__device__ __forceinline__ VisRec load_rec(const VisRec *__restrict__ recs, int idx, const Geom &g, bool *clamped = nullptr)
+__device__ __forceinline__ VisRec load_rec(const RecWord *__restrict__ recs, int idx, const Geom &g, bool *clamped = nullptr)
 {
     // (streamed once or twice and never again: non-temporal, so that the records do not push kernel taps out of L2)
-    const int32_t *p = reinterpret_cast<const int32_t *>(recs + idx);
-    const int32_t a = __builtin_nontemporal_load(p), k = __builtin_nontemporal_load(p + 1), o = __builtin_nontemporal_load(p + 2);
+    const RecWord w = __builtin_nontemporal_load(recs + idx);
+    const int sk = g.ob, sx = g.ob + g.kb;
+    const int32_t o = (int32_t)(w & ((1ull << sk) - 1)), k = (int32_t)((w >> sk) & ((1ull << g.kb) - 1));
+    const int32_t lx = (int32_t)(w >> sx) & 0x7f, ly = (int32_t)(w >> (sx + 7)) & 0x7f;
     VisRec r;
-    const int32_t lx = min(a & 0xffff, g.Tx - 1), ly = min((a >> 16) & 0xffff, g.Ty - 1);
-    r.lxy = (ly << 16) | lx;
-    r.kslice = min(max(k, 0), g.nslices - 1);
-    r.orig = min(max(o, 0), g.nvis - 1);
-    if (clamped) *clamped = r.lxy != a || r.kslice != k || r.orig != o;
+    r.lxy = (min(ly, g.Ty - 1) << 16) | min(lx, g.Tx - 1);
+    r.kslice = min(k, g.nslices - 1);
+    r.orig = min(o, g.nvis - 1);
+    if (clamped) *clamped = r.lxy != ((ly << 16) | lx) || r.kslice != k || r.orig != o || (w >> (sx + 14)) != 0;
     return r;
 }
 

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) clear_ints_kernel(int32_t *a, int na, int
 // S == 0: any gh x gw.
 // DBG (tuning builds only): 1 = skip the LDS atomics, 2 = every visibility reads slice 0, 3 = both.
 template <int S, int DBG>
-__global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *__restrict__ recs,
+__global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const RecWord *__restrict__ recs,
                                                          const int32_t *__restrict__ bin_start,
                                                          const int32_t *__restrict__ work_start,
                                                          const double2 *__restrict__ gcf,
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(1024) tile_grid_kernel(Geom g, const VisRec *_
 
 // Gather twin: vis_out[orig] = sum_ij gcf[kslice][i][j] * G[y0+i][x0+j]; the tile (zero outside
 // the grid) is staged in LDS once per work item, taps are summed across the wave.
-__global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const VisRec *__restrict__ recs,
+__global__ void __launch_bounds__(1024) tile_degrid_kernel(Geom g, const RecWord *__restrict__ recs,
                                                            const int32_t *__restrict__ bin_start,
                                                            const int32_t *__restrict__ work_start,
                                                            const double2 *__restrict__ gcf,
@@ -282,7 +282,7 @@ int launch_tile_grid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_byte
                      const double *gcf, const double *vis, double *grid)
 {
     Tables t = tables_of(ctx, g);
-    const VisRec *recs = (const VisRec *)ctx->recs.ptr;
+    const RecWord *recs = (const RecWord *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
 #define GH_LAUNCH(S_, D_)                                                                                   \
     do {                                                                                                    \
@@ -319,7 +319,7 @@ int launch_tile_degrid(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_by
                        const double *gcf, const double *grid, double *vis_out)
 {
     Tables t = tables_of(ctx, g);
-    const VisRec *recs = (const VisRec *)ctx->recs.ptr;
+    const RecWord *recs = (const RecWord *)ctx->recs.ptr;
     const dim3 gr(work_blocks(g, n)), bl(block);
     GH_CHECK(raise_lds(ctx, tile_degrid_kernel));
     hipLaunchKernelGGL(tile_degrid_kernel, gr, bl, lds_bytes, ctx->stream, g, recs, t.bin_start, t.work_start,

@@ -53,7 +53,7 @@ struct SortedItem {
 // residue) and the sorted list carries the kslice itself in place of `orig`, which gridding does not need; a run
 // is a stretch of equal kslice.
 template <int S, bool DEGRID, int ABL = 0, bool AW = false>
-__global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const VisRec *__restrict__ recs,
+__global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const RecWord *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
                                                                 const int32_t *__restrict__ work_start,
                                                                 const double2 *__restrict__ gcf,
@@ -621,7 +621,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
                             int64_t n, const double *gcf, const double *vis, double *grid, bool degrid)
 {
     Tables t = tables_of(ctx, g);
-    const VisRec *recs = (const VisRec *)ctx->recs.ptr;
+    const RecWord *recs = (const RecWord *)ctx->recs.ptr;
     if (g.chunk > batch) return fail(ctx, GRIDHIP_EINVAL, "sorted kernel: chunk %d exceeds its work-item capacity %d", g.chunk, batch);
     if (g.per_vis && degrid) return fail(ctx, GRIDHIP_EUNSUPPORTED, "no degrid form of the aw tile kernel");
     // persistent work-groups: as many as can be resident (LDS-limited), pulling items from per-group queues

@@ -42,7 +42,7 @@ def make_case(seed):
     if rng.random() < 0.5:
         opts["chunk"] = int(rng.choice([64, 100, 1000, 5000]))
     opts["sort"] = int(rng.choice([0, 1, 2]))
-    opts["prepass"] = int(rng.choice([0, 1, 2, 4, 5]))  # one- or two-level scatter in the binning pre-pass (and its variants)
+    opts["prepass"] = int(rng.choice([0, 1, 2, 4, 5, 6]))  # one- or two-level scatter in the binning pre-pass (and its variants)
     return (H, Wd, gcf, u, v, wb, vis, opts)
 
 

@@ -106,13 +106,15 @@ def test_sorted_variant_matches_oracle(ctx, oracle, dist):
                                    (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 16, "wgroups": 8}),  # 4 counting windows, 136 coarse-bin width
                                    (2048, 2048, 8, 2, 7, 7, 300000, {"tile": 8, "wgroups": 4}),  # 264 196 bins > 2^18: 16-byte intermediate records
                                    (64, 64, 1, 1, 1, 1, 1000, {}), (200, 200, 2, 2, 31, 31, 2000, {})])
-@pytest.mark.parametrize("dist,mode", [("uniform", 2), ("core", 2), ("uniform", 4), ("core", 5)])
+@pytest.mark.parametrize("dist,mode", [("uniform", 2), ("core", 2), ("uniform", 4), ("core", 5), ("uniform", 6)])
 def test_two_level_prepass(ctx, oracle, shape, dist, mode):
     """The scatter of the binning pre-pass in two levels (LDS-sorted runs into coarse bins, then to the bins):
     automatic from 2^22 visibilities, forced here on small streams.  Coordinates spill over the grid edges
     (dropped visibilities leave holes in neither level) and some wbins are out of range.
-    mode 2: the scatter reads the counting sweep's 8-byte pre-records and moves 12-byte records; 4: it recomputes
-    from the stream; 5: 16-byte intermediate records."""
+    mode 2: the scatter reads the counting sweep's 8-byte pre-records and moves 8-byte records (the bin's index
+    inside its coarse bin rides in the word's spare bits, the coarse bin follows from the record's position);
+    4: it recomputes from the stream; 5, 6: 16- and 12-byte intermediate records (what streams whose fields leave no
+    spare bits use)."""
     N, M, W, Q, gh, gw, n, opts = shape
     gcf, u, v, wb, vis = case(1234 + N, N, M, W, Q, gh, gw, n, spread=0.6, dist=dist)
     wb = wb.copy()
@@ -140,6 +142,29 @@ def test_two_level_prepass(ctx, oracle, shape, dist, mode):
     dref = oracle.degrid2(gcf, ref, u[keep], v[keep], wb[keep])
     assert rel(d[keep], dref) < TOL
     assert np.all(d[~keep] == 0)
+
+
+@pytest.mark.parametrize("prepass", [1, 2])
+def test_calls_whose_record_fields_do_not_fit_are_cut_into_parts(ctx, oracle, prepass):
+    """A record is one 64-bit word (14 bits of footprint origin, the kernel slice, the visibility's index); a call
+    with slices x visibilities above 2^50 is gridded / degridded in parts.  The test hook "rec_bits" pretends the
+    word has 30 bits, so that this case (7 bits of slice, 16 of index) is cut into parts of 512 visibilities."""
+    N, W, Q, S, n = 128, 8, 4, 7, 40000
+    gcf, u, v, wb, vis = case(515, N, N, W, Q, S, S, n, spread=0.55)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+    rng = np.random.default_rng(4)
+    G = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    dref = oracle.degrid2(gcf, G, u, v, wb)
+    try:
+        ctx.set_option("prepass", prepass)
+        ctx.set_option("rec_bits", 30)
+        got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+        d = ctx.degrid2(gcf, G, (u, v, None), wb)
+        errors = ctx.get_option("errors")
+    finally:
+        ctx.set_option("prepass", 0)
+        ctx.set_option("rec_bits", 0)
+    assert errors == 0 and rel(got, ref) < TOL and rel(d, dref) < TOL
 
 
 @pytest.mark.parametrize("opts", [{"tile": 16, "wgroups": 4}, {"tile": 16, "wgroups": 8}, {"tile": 8, "wgroups": 8}])
@@ -513,7 +538,7 @@ def test_device_path_can_be_captured_into_a_hip_graph(ctx, prepass, S):
     assert max(errs) < 1e-12 and errors == 0
 
 
-@pytest.mark.parametrize("mode,n", [(1, 20000), (2, 200000), (4, 200000), (5, 200000), (3, 20000)])
+@pytest.mark.parametrize("mode,n", [(1, 20000), (2, 200000), (4, 200000), (5, 200000), (6, 200000), (3, 20000)])
 def test_record_writes_are_bounded_by_the_array(ctx, oracle, mode, n):
     """Every record store of the pre-pass is checked against the record array's capacity.  The test hook
     "fault_inject" hides the last k slots from the scatter (a deliberately short table): nothing is written beyond
