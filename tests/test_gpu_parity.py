@@ -90,7 +90,7 @@ def test_sorted_variant_matches_oracle(ctx, oracle, dist):
                             (256, 8, 4, 11, 60000), (256, 8, 2, 13, 60000), (200, 4, 4, 5, 50000),
                             (256, 8, 2, 8, 60000), (256, 8, 2, 14, 60000), (256, 4, 2, 16, 60000)]:
         gcf, u, v, wb, vis = case(7 + N, N, N, W, Q, S, S, n, dist=dist)
-        ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+        ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
         ctx.set_option("sort", 1)
         try:
             got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
@@ -121,7 +121,7 @@ def test_two_level_prepass(ctx, oracle, shape, dist, mode):
     wb[::97] = W + 3      # dropped and counted
     wb[5::101] = -1
     keep = (wb >= 0) & (wb < W)
-    ref = oracle.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), u[keep], v[keep], wb[keep], vis[keep], mt_mode=1)
+    ref = oracle.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), u[keep], v[keep], wb[keep], vis[keep], mt_mode=2)
     try:
         ctx.set_option("prepass", mode)
         for k, val in opts.items():
@@ -151,7 +151,7 @@ def test_calls_whose_record_fields_do_not_fit_are_cut_into_parts(ctx, oracle, pr
     word has 30 bits, so that this case (7 bits of slice, 16 of index) is cut into parts of 512 visibilities."""
     N, W, Q, S, n = 128, 8, 4, 7, 40000
     gcf, u, v, wb, vis = case(515, N, N, W, Q, S, S, n, spread=0.55)
-    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
     rng = np.random.default_rng(4)
     G = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
     dref = oracle.degrid2(gcf, G, u, v, wb)
@@ -173,7 +173,7 @@ def test_many_bins_windowed_prepass(ctx, oracle, opts):
     and past 8 windows counts in global memory (the 8x8-tile case)."""
     N, W, Q, S, n = 2048, 8, 2, 7, 300000
     gcf, u, v, wb, vis = case(31, N, N, W, Q, S, S, n, spread=0.5)
-    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
     try:
         for k, val in opts.items():
             ctx.set_option(k, val)
@@ -548,7 +548,7 @@ def test_record_writes_are_bounded_by_the_array(ctx, oracle, mode, n):
     import torch
     N, W, Q, S = 256, 8, 4, 9
     gcf, u, v, wb, vis = case(77, N, N, W, Q, S, S, n, spread=0.45)
-    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
     dev = torch.device("cuda:0")
     t = lambda a: torch.from_numpy(a).to(dev)
     hide = 1000
@@ -604,7 +604,7 @@ def test_baseline_config2_full_size(ctx, oracle):
     """BASELINE.json configs[1]: 10^6 vis, 2048^2 grid, 7x7 support — small enough to compare outright."""
     N, W, Q, S, n = 2048, 16, 8, 7, 1_000_000
     gcf, u, v, wb, vis = case(2026, N, N, W, Q, S, S, n, spread=0.49)
-    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=1)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
     got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
     assert rel(got, ref) < TOL
 
