@@ -609,6 +609,37 @@ def test_baseline_config2_full_size(ctx, oracle):
     assert rel(got, ref) < TOL
 
 
+def test_bench_workload_against_the_oracle_outright(ctx, oracle):
+    """BASELINE.json configs[2] - the very stream and kernel table bench.py times (10^8 visibilities, 4096^2, 128
+    planes, 15x15, Q = 8; bench.synth_vis / synth_kernels with the bench's seed) - gridded by the GPU and by the CPU
+    oracle in its owner-computes mode (bit-identical to the serial oracle, tests/test_oracle.py), compared cell by
+    cell.  The oracle runs at ~16 Mvis/s on the GPU box's 128 host threads; with fewer than 32 the stream is cut to
+    2 x 10^7 visibilities so that the test stays within a minute."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda:0")
+    n, N, W, Q, S = bench.WORKLOADS["cfg3"]
+    if (os.cpu_count() or 1) < 32:
+        n = 20_000_000
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    u, v, wb, vis = bench.synth_vis(n, N, W, S, 0x5EEDC0DE, dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+    torch.cuda.synchronize()
+    assert ctx.get_option("errors") == 0 and ctx.last_dropped() == 0
+    got = G.cpu().numpy()
+    d = ctx.degrid2(gcf, G, (u, v, None), wb)       # the adjoint pass over the same stream, checked on a sample
+    ref = oracle.convgrid2(gcf.cpu().numpy(), np.zeros((N, N), dtype=np.complex128), u.cpu().numpy(), v.cpu().numpy(),
+                           wb.cpu().numpy(), vis.cpu().numpy(), mt_mode=2)
+    assert rel(got, ref) < TOL
+    k = slice(0, 200_000)
+    dref = oracle.degrid2(gcf.cpu().numpy(), ref, u[k].cpu().numpy(), v[k].cpu().numpy(), wb[k].cpu().numpy())
+    assert rel(d[k].cpu().numpy(), dref) < TOL
+
+
 @pytest.mark.parametrize("N,n", [(2048, 4_000_000), (4096, 100_000_000), (8192, 20_000_000)])
 def test_checksum_property_large(ctx, N, n):
     """Size-independent checks at BASELINE.json's full sizes (configs[2]: 10^8 vis on 4096^2; the
