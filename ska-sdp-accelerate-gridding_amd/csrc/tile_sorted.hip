@@ -90,6 +90,11 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
     double2 *svals_wg = sorted_vals + (size_t)blockIdx.x * 2 * batch;
     uint2 *smo_wg = sorted_mo + (size_t)blockIdx.x * 2 * batch;
 
+    // Where a record's visibility value comes from.  w-projection gridding: the walkers gather it themselves from the
+    // caller's array, a block of 64 records ahead of its use - the sorted list then carries 8 bytes per record and the
+    // values cross the memory system once.  aw gridding: the list's second word is the kernel's index, so the sorter
+    // gathers the values and stages them next to the list (16 bytes more per record, written and read back).
+    constexpr bool STAGE_VALS = !DEGRID && AW;
     const bool solo = nw == 1;
     const bool is_sorter = wave == nw - 1;
     // the sorter is the youngest wave of its SIMD, i.e. last at the arbiter, and its work is a chain of latencies:
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
             bool off[8];  // a field of the record was out of range (stale slot): not staged, counted
 #pragma unroll
             for (int q = 0; q < 8; ++q) rec[q] = load_rec(recs, b_lo + min(r0 + q * 64, cnt - 1), g, &off[q]);
-            if (!DEGRID) {
+            if (STAGE_VALS) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) val[q] = (ABL & 8) ? make_double2(1.0, (double)q) : load_nt(vis + rec[q].orig);
             }
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                     // meta = slice key | the footprint origin's cell offset in the tile (< 8192: sorted_plan)
                     smo[pos] = make_uint2(((uint32_t)key << 16) | (uint32_t)((rec[q].lxy >> 16) * g.ldw + (rec[q].lxy & 0xffff)),
                                           (uint32_t)(AW ? rec[q].kslice : rec[q].orig));
-                    if (!DEGRID) svals[pos] = val[q];
+                    if (STAGE_VALS) svals[pos] = val[q];
                 } else
                     ++bad;
             }
@@ -266,10 +271,13 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
             seg_hi = (int)(((int64_t)staged * (wave + 1)) / nwalk);
         }
         if (seg_lo >= seg_hi) return;
-        auto load_block = [&](int b0, uint2 &mo, double2 &v) {
+        auto load_list = [&](int b0, uint2 &mo, double2 &v) {
             const int idx = max(min(b0 + lane, seg_hi - 1), seg_lo);  // past the end: the piece's last record
             mo = smo[idx];
-            if (!DEGRID) v = svals[idx];
+            if (STAGE_VALS) v = svals[idx];
+        };
+        auto load_value = [&](const uint2 &mo, double2 &v) {  // (mo.y = orig, brought below nvis by the sorter)
+            if (!DEGRID && !STAGE_VALS) v = (ABL & 8) ? make_double2(1.0, 2.0) : load_nt(vis + mo.y);
         };
         auto issue = [&](double2(&k)[NSTEP], int key, int len) {
             key = min(max(key, 0), (AW ? g.nslices : nkeys) - 1);  // never form an address outside the kernel table
@@ -287,13 +295,19 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
             for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lofs];
             k[NSTEP - 1] = kp[lt];
         };
-        uint2 moN;
-        double2 vN = make_double2(0.0, 0.0);
-        load_block(seg_lo, moN, vN);
+        // two blocks of the list and one block of values are in flight ahead of the block being accumulated
+        uint2 moN, moNN;
+        double2 vN = make_double2(0.0, 0.0), vNN = make_double2(0.0, 0.0);
+        load_list(seg_lo, moN, vN);
+        load_list(seg_lo + 64, moNN, vNN);
+        load_value(moN, vN);
         for (int b0 = seg_lo; b0 < seg_hi; b0 += 64) {
             const uint2 mo = moN;
             const double2 vB = vN;
-            load_block(b0 + 64, moN, vN);  // the next block's records travel while this one is accumulated
+            moN = moNN;
+            vN = vNN;
+            load_value(moN, vN);                      // the next block's values (its list entries arrived a block ago) ...
+            load_list(b0 + 128, moNN, vNN);           // ... and the list entries of the one after travel meanwhile
             const int bcnt = min(64, seg_hi - b0);
             const uint32_t mykey = AW ? mo.y : mo.x >> 16;
             const uint32_t prevkey = (uint32_t)__shfl_up((int)mykey, 1, 64);
