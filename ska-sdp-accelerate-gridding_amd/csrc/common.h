@@ -49,6 +49,7 @@ struct Geom {
     // fgh x fgw is the kernel the caller passed (the footprint origin is x - fgw / 2, y - fgh / 2).
     int32_t fgh, fgw, px, py, P;
     int32_t ob, kb;       // record layout: bits of the orig and kslice fields (set_rec_bits)
+    int32_t dense;        // 1: two or more visibilities per kernel slice and tile on average (walker weights, tile_sorted.hip)
     // division by Tx, Ty, W, P, px in the counting sweep without a divide: x / d == umulhi(x, m) >> s for 0 <= x < 2^31
     // (set_div_magic; the sweep is bound by its instruction count, and a 32-bit divide is ~30 instructions)
     uint32_t mTx, mTy, mW, mP, mPx;

@@ -173,6 +173,7 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->ngroups = ng;
     g->nbins = ng * g->ntiles;
     set_div_magic(g);
+    g->dense = n >= 2 * (int64_t)g->ntiles * W * Q * Q ? 1 : 0;
 
     int chunk = (int)ctx->opt.chunk;
     if (chunk == 0) chunk = 8192;

@@ -39,9 +39,14 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // store) disappear behind it.  A work-group of one wave does both, one after the other.
 constexpr int SORTED_IM_OFF = 65528;  // largest multiple of 8 that a DS instruction's offset field holds
 
-// piece boundaries of the 15 walkers in 1/1024ths of the sorted list: weights 1.55 (walkers 0..3), 1.14 (4..7),
-// 0.71 (8..11), 0.48 (12..14) of an equal share (five rounds of weight / measured finishing time: all within 6 %)
-__device__ const int cut15[16] = {0, 106, 211, 317, 422, 500, 578, 655, 733, 781, 829, 877, 926, 958, 991, 1024};
+// piece boundaries of the 15 walkers in 1/1024ths of the sorted list.  The SIMD arbiter favours its oldest wave, so with
+// equal pieces walkers 0..3 finish at 0.55 of the walk and the last three run on with the LDS unit half idle: the
+// pieces are weighted - 1.6 (walkers 0..3), 1.17 (4..7), 0.69 (8..11), 0.40 (12..14) of an equal share where the
+// LDS unit binds (rounds of weight / measured finishing time until all walkers were within 4 %: 10.77 -> 10.54 ms at
+// cfg3), and the flatter 1.55 / 1.14 / 0.71 / 0.48 where items are sparse and the walkers wait for taps instead
+// (Geom.dense = 0: fewer than two visibilities per slice and tile; the first table costs 0.5 % there).
+__device__ const int cut15[2][16] = {{0, 106, 211, 317, 422, 500, 578, 655, 733, 781, 829, 877, 926, 958, 991, 1024},
+                                     {0, 108, 221, 329, 434, 513, 596, 677, 754, 800, 852, 898, 943, 969, 998, 1024}};
 
 struct SortedItem {
     int32_t valid, tile, grp, staged;
@@ -264,8 +269,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
         // cut[w] / 1024 = share of the list in front of walker w (option dbg = 256: equal pieces, for comparison).
         int seg_lo, seg_hi;
         if (nwalk == 15 && !DEGRID && !(g.dbg & 256)) {  // (degrid2 measured 0.5 % slower with them)
-            seg_lo = (int)(((int64_t)staged * cut15[wave]) >> 10);
-            seg_hi = (int)(((int64_t)staged * cut15[wave + 1]) >> 10);
+            seg_lo = (int)(((int64_t)staged * cut15[g.dense][wave]) >> 10);
+            seg_hi = (int)(((int64_t)staged * cut15[g.dense][wave + 1]) >> 10);
         } else {
             seg_lo = (int)(((int64_t)staged * wave) / nwalk);
             seg_hi = (int)(((int64_t)staged * (wave + 1)) / nwalk);
