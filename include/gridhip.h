@@ -88,6 +88,7 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               the visibilities that share it reuse it; 0 = one kernel per visibility (as the reference evaluates)
  *   "fault_inject"  TEST HOOK: hides the last k slots of the record array from the pre-pass's scatter so that its
  *               bounds checks have something to reject (counted in "errors"; results are then incomplete)
+ *   "wtable"    which table of walker weights the tap-reusing kernel uses: 0 = auto, 1 = flat, 2 = steep (tile_sorted.hip)
  *   "rec_bits"  TEST HOOK: pretend the 64-bit record word has this many bits (16..63), so that small calls take the
  *               path that grids a call in several parts (taken for real above 2^50 slices x visibilities)
  *   ("dbg", the ablation / profiling switch of tuning runs, exists only in the tuning build of the library,

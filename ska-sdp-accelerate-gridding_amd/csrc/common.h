@@ -49,7 +49,7 @@ struct Geom {
     // fgh x fgw is the kernel the caller passed (the footprint origin is x - fgw / 2, y - fgh / 2).
     int32_t fgh, fgw, px, py, P;
     int32_t ob, kb;       // record layout: bits of the orig and kslice fields (set_rec_bits)
-    int32_t dense;        // 1: two or more visibilities per kernel slice and tile on average (walker weights, tile_sorted.hip)
+    int32_t dense;        // which table of walker weights (tile_sorted.hip): 1 = the steep one (make_geom)
     // division by Tx, Ty, W, P, px in the counting sweep without a divide: x / d == umulhi(x, m) >> s for 0 <= x < 2^31
     // (set_div_magic; the sweep is bound by its instruction count, and a 32-bit divide is ~30 instructions)
     uint32_t mTx, mTy, mW, mP, mPx;
@@ -107,7 +107,7 @@ __host__ __device__ __forceinline__ RecWord rec_pack(const Geom &g, int32_t lxy,
 }
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0, rec_bits = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0, rec_bits = 0, wtable = 0;
 };
 
 struct Workspace {

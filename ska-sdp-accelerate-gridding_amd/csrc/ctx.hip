@@ -173,7 +173,9 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->ngroups = ng;
     g->nbins = ng * g->ntiles;
     set_div_magic(g);
-    g->dense = n >= 2 * (int64_t)g->ntiles * W * Q * Q ? 1 : 0;
+    // which table of walker weights (tile_sorted.hip): the steeper one where the LDS unit binds - supports 15 and 16 with two
+    // or more visibilities per slice and tile; measured per support, option "wtable" forces 1 = flat, 2 = steep
+    g->dense = ctx->opt.wtable ? (ctx->opt.wtable == 2 ? 1 : 0) : (gh >= 15 && n >= 2 * (int64_t)g->ntiles * W * Q * Q) ? 1 : 0;
 
     int chunk = (int)ctx->opt.chunk;
     if (chunk == 0) chunk = 8192;
@@ -335,6 +337,7 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "scatter_chunk")) return &ctx->opt.scatter_chunk;
     if (!strcmp(key, "count_unroll")) return &ctx->opt.count_unroll;
     if (!strcmp(key, "rec_bits")) return &ctx->opt.rec_bits;
+    if (!strcmp(key, "wtable")) return &ctx->opt.wtable;
     return nullptr;
 }
 
