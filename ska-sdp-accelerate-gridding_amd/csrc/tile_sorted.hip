@@ -459,8 +459,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                         const int row = lane >> 4;
                         if ((lane & 15) == 15 && i + row < len) {
                             const int32_t o = row == 0 ? oo[0] : row == 1 ? oo[1] : row == 2 ? oo[2] : oo[3];
-                            if (g.P == 1)
-                                vis[o] = make_double2(rr, ri);
+                            if (g.P == 1)  // (written once, never read here: past the L2's taps)
+                                __builtin_nontemporal_store(dvec2_t{rr, ri}, reinterpret_cast<dvec2_t *>(vis + o));
                             else {  // sub-footprints: a visibility's parts are summed (vis_out was cleared)
                                 double *dst = reinterpret_cast<double *>(vis + o);
                                 unsafeAtomicAdd(dst, rr);
