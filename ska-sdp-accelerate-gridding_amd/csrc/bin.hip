@@ -193,7 +193,7 @@ __device__ __forceinline__ void block_range(int64_t n, int64_t *lo, int64_t *hi)
     if (*lo > n) *lo = n;
 }
 
-template <bool LDS_HIST, int UN = 1>
+template <bool LDS_HIST, int UN = 1, bool V2 = false>
 __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, const double *__restrict__ u,
                                                          const double *__restrict__ v, int64_t stride,
                                                          const int64_t *__restrict__ wbin,
@@ -217,6 +217,52 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
     int dropped = 0;
     const bool from_pre = pre && pf.bin_bits < 0;
     const PreFmt rf = {from_pre ? -pf.bin_bits : pf.bin_bits};
+    auto tally = [&](const BinOut &b) {
+        if (b.bin >= 0) {
+            if (LDS_HIST) {
+                if (b.bin >= bin_lo && b.bin < bin_hi) atomicAdd(&hist[b.bin - bin_lo], 1);
+            } else
+                atomicAdd(&bin_count[b.bin], 1);
+        } else if (b.bin == -2)
+            ++dropped;
+    };
+    // V2 (unit stride, one record per visibility, 16-byte aligned arrays - the launcher checks): a thread takes two
+    // consecutive visibilities, so every access of the sweep is a 16-byte one (u, v, wbin read, pre-records written),
+    // and the work-groups take the stream grid-stride instead of one contiguous slice each.  The wider accesses alone
+    // measured nothing; the grid-stride order took the sweep from 0.70 to 0.62 ms (256 x 4 concurrent streams become
+    // four narrow windows: HBM page locality).  The same order in the coarse scatter measured no difference.
+    if (V2 && !from_pre) {
+        hi = n;
+        for (int64_t k0 = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); k0 < hi; k0 += 2 * (int64_t)gridDim.x * blockDim.x) {
+            const bool two = k0 + 1 < hi;
+            double2 pu, pv;
+            longlong2 wb = make_longlong2(0, 0);
+            if (two) {
+                pu = *reinterpret_cast<const double2 *>(u + k0);
+                pv = *reinterpret_cast<const double2 *>(v + k0);
+                if (wbin) wb = *reinterpret_cast<const longlong2 *>(wbin + k0);
+            } else {
+                pu = make_double2(u[k0], 0.0);
+                pv = make_double2(v[k0], 0.0);
+                if (wbin) wb.x = wbin[k0];
+            }
+            const BinOut b0 = vis_bin(g, pu.x, pv.x, wb.x, k0, 0);
+            BinOut b1 = vis_bin(g, pu.y, pv.y, wb.y, k0 + 1, 0);
+            if (!two) b1.bin = -1;
+            if (pre) {
+                if (two)
+                    *reinterpret_cast<ulonglong2 *>(pre + k0) = make_ulonglong2(pre_pack(rf, b0), pre_pack(rf, b1));
+                else
+                    pre[k0] = pre_pack(rf, b0);
+            }
+            if (zero_out) {
+                if (b0.bin < 0) zero_out[k0] = make_double2(0.0, 0.0);
+                if (two && b1.bin < 0) zero_out[k0 + 1] = make_double2(0.0, 0.0);
+            }
+            tally(b0);
+            tally(b1);
+        }
+    } else
     // four visibilities per thread and trip: their 12 loads are in flight together (one work-group per CU has
     // nothing else to cover the memory latency with)
     for (int64_t k0 = lo + threadIdx.x; k0 < hi; k0 += (int64_t)UN * blockDim.x) {
@@ -255,15 +301,7 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
             }
         }
 #pragma unroll
-        for (int q = 0; q < UN; ++q) {
-            if (b[q].bin >= 0) {
-                if (LDS_HIST) {
-                    if (b[q].bin >= bin_lo && b[q].bin < bin_hi) atomicAdd(&hist[b[q].bin - bin_lo], 1);
-                } else
-                    atomicAdd(&bin_count[b[q].bin], 1);
-            } else if (b[q].bin == -2)
-                ++dropped;
-        }
+        for (int q = 0; q < UN; ++q) tally(b[q]);
     }
     if (dropped && bin_lo == 0) atomicAdd(&scalars[0], dropped);
     if (LDS_HIST) {
@@ -592,7 +630,7 @@ __global__ void __launch_bounds__(NT, 4) coarse_scatter_kernel(Geom g, int64_t n
     if (bad) atomicAdd(&scalars[2], bad);
 }
 
-// Level 2.  Work-group w takes the w-th equal share of tmp in chunks of CHUNK records.  tmp is ordered by
+// Level 2.  The work-groups take tmp in chunks of CHUNK records, dealt round-robin.  tmp is ordered by
 // coarse bin, so a chunk's bins lie between the coarse bins of its first and last record: normally one or two
 // coarse bins, i.e. at most a few hundred bins.  The chunk is counting-sorted by bin in LDS exactly as level 1 sorts
 // by coarse bin, each bin's range is reserved with one global atomic, and the records leave as runs.  A chunk that
@@ -635,9 +673,10 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
     const RecWord lowmask = (1ull << fbit) - 1, fmask = (1ull << shift) - 1;
     int64_t ntot = bin_start[g.nbins];
     if (ntot > cap) ntot = cap;  // (level 1 has written nothing beyond `cap`)
-    int64_t per = (ntot + gridDim.x - 1) / gridDim.x;
-    per = (per + CHUNK - 1) / CHUNK * CHUNK;
-    const int64_t lo = min((int64_t)blockIdx.x * per, ntot), hi = min(lo + per, ntot);
+    // chunks are dealt round-robin to the work-groups: at any moment they read one narrow window of tmp and write into
+    // the output range of the one or two coarse bins it belongs to (1.50 -> 1.45 ms for the pre-pass against one
+    // contiguous share per work-group; the bins' cursors see no more contention than they did)
+    const int64_t lo = min((int64_t)blockIdx.x * CHUNK, ntot), hi = ntot, fstep = (int64_t)gridDim.x * CHUNK;
     int bad = 0;
     if (FMT == 8) {
         for (int t = tid; t < ncoarse; t += NT) cend[t] = bin_start[min((t + 1) << shift, g.nbins)];
@@ -670,7 +709,7 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
 #pragma unroll
         for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(lo + q * NT + tid, hi - 1)];  // (unconditional: indices clamped)
     }
-    for (int64_t c0 = lo; c0 < hi; c0 += CHUNK) {
+    for (int64_t c0 = lo; c0 < hi; c0 += fstep) {
         const int64_t c1 = min(c0 + CHUNK, hi);
         if (!PREF) {
 #pragma unroll
@@ -722,7 +761,7 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
             }
             if (PREF) {
 #pragma unroll
-                for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
+                for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + fstep + q * NT + tid, hi - 1)];
             }
             lds_barrier();  // (wtot[24], [25] are rewritten by the next chunk)
             continue;
@@ -747,7 +786,7 @@ __global__ void __launch_bounds__(NT, 4) fine_scatter_kernel(Geom g, const int32
         }
         if (PREF) {
 #pragma unroll
-            for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + CHUNK + q * NT + tid, hi - 1)];
+            for (int q = 0; q < PER; ++q) nxt[q] = tmp[min(c0 + fstep + q * NT + tid, hi - 1)];
         }
 #pragma unroll
         for (int q = 0; q < PER; ++q) rank[q] = key[q] >= 0 ? atomicAdd(&hist[key[q]], 1) : 0;
@@ -849,6 +888,8 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
                                               hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
         GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true, 4>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
+        GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_count_kernel<true, 1, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
         GH_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)bin_scatter_kernel<true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, ctx->max_lds));
         ctx->attr_mask |= 1u;
@@ -893,7 +934,13 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
             // four visibilities per thread and trip when the bins take several windows: the windows after the first
             // read nothing but 8-byte pre-records and gain from more loads in flight (8192^2, three windows: 2.8 -> 2.6 ms;
             // one window, 4096^2: no difference).  Option count_unroll: 4 = always, 1 = never.
-            if (ctx->opt.count_unroll == 4 || (ctx->opt.count_unroll == 0 && windows > 1))
+            const bool v2 = wdw == 0 && pre && uv_stride == 1 && g.P == 1 && ctx->opt.count_unroll != 1 &&
+                            (((uintptr_t)u | (uintptr_t)v | (uintptr_t)wbin | (uintptr_t)pre) & 15) == 0;
+            if (v2)
+                hipLaunchKernelGGL((bin_count_kernel<true, 1, true>), dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
+                                   uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
+                                   PreFmt{bb}, pre, zero_out);
+            else if (ctx->opt.count_unroll == 4 || (ctx->opt.count_unroll == 0 && windows > 1))
                 hipLaunchKernelGGL((bin_count_kernel<true, 4>), dim3(blocks), dim3(threads), hist_bytes, ctx->stream, g, n, u, v,
                                    uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
                                    PreFmt{wdw == 0 ? bb : -bb}, pre, zero_out);
