@@ -262,10 +262,17 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
             tally(b0);
             tally(b1);
         }
-    } else
-    // four visibilities per thread and trip: their 12 loads are in flight together (one work-group per CU has
-    // nothing else to cover the memory latency with)
-    for (int64_t k0 = lo + threadIdx.x; k0 < hi; k0 += (int64_t)UN * blockDim.x) {
+    } else {
+    // UN visibilities per thread and trip: their loads are in flight together (one work-group per CU has
+    // nothing else to cover the memory latency with).
+    // (two-level scatter, block_hist == null: nothing ties a work-group to a slice of the stream, so this loop too runs
+    // grid-stride; the one-level scatter needs each work-group to see the same slice in both of its sweeps)
+    if (!block_hist) {
+        lo = (int64_t)blockIdx.x * UN * blockDim.x;
+        hi = n;
+    }
+    const int64_t kstep = block_hist ? (int64_t)UN * blockDim.x : (int64_t)gridDim.x * UN * blockDim.x;
+    for (int64_t k0 = lo + threadIdx.x; k0 < hi; k0 += kstep) {
         BinOut b[UN];
         if (from_pre) {
             unsigned long long p[UN];
@@ -302,6 +309,7 @@ __global__ void __launch_bounds__(1024) bin_count_kernel(Geom g, int64_t n, cons
         }
 #pragma unroll
         for (int q = 0; q < UN; ++q) tally(b[q]);
+    }
     }
     if (dropped && bin_lo == 0) atomicAdd(&scalars[0], dropped);
     if (LDS_HIST) {
