@@ -653,10 +653,12 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     const int most = work_blocks(g, n);
     if (nblk > most) nblk = most > g.ngroups ? (most / g.ngroups) * g.ngroups : g.ngroups;
     const dim3 gr(nblk), bl(block);
-    // two sorted lists (current item, next item) per resident work-group: 16 B value + 8 B (meta, orig) per record
-    GH_CHECK(ws_reserve(ctx, ctx->sorted, (size_t)nblk * 2 * batch * 24));
-    double2 *svals = (double2 *)ctx->sorted.ptr;
-    uint2 *smo = (uint2 *)(svals + (size_t)nblk * 2 * batch);
+    // two sorted lists (current item, next item) per resident work-group: 8 B (meta, orig) per record, and for the aw
+    // gridders, whose sorter stages the values, 16 B more
+    const size_t nlist = (size_t)nblk * 2 * batch, nvals = g.per_vis ? nlist : 0;
+    GH_CHECK(ws_reserve(ctx, ctx->sorted, nvals * 16 + nlist * 8));
+    double2 *svals = (double2 *)ctx->sorted.ptr;  // (not dereferenced when nothing is staged)
+    uint2 *smo = (uint2 *)(svals + nvals);
     launch_clear(ctx, t.scalars + 4, 16, (g.dbg & 16) ? t.scalars + 32 : nullptr, (g.dbg & 16) ? 64 : 0);  // the w-groups' queues
 #define GH_LAUNCH(S_, D_)                                                                                        \
     do {                                                                                                         \
