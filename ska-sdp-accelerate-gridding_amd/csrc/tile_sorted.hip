@@ -2,19 +2,20 @@
 //
 // The plain tile kernel streams one [S][S] kernel slice (3.6 KB at 15x15) from L2 for every
 // visibility; at 10^8 visibilities that L2->CU stream (360 GB) is what bounds it.  Within one
-// work item (w-group x tile, ~3000 visibilities) only ~1000 distinct slices occur, so this
+// work item (w-group x tile, 4000 - 8000 visibilities) only ~1000 distinct slices occur, so this
 // variant first orders the work item's records by slice (counting sort: LDS histogram, scan,
 // scatter) and each wave then walks a contiguous piece of the sorted list run by run, keeping a
 // run's taps in registers and fetching the next runs' taps while the current run is accumulated.
-// Tap traffic drops by the mean run length (~3x on the uniform benchmark; far more on real,
+// Tap traffic drops by the mean run length (4 - 8x on the uniform benchmark; far more on real,
 // w-coherent data).
 //
-// Where things live (T=64, 15x15): LDS holds the tile (98.6 KB, resident for the whole work item,
-// flushed once) and the sort's histogram (4.1 KB).  The sorted list itself - per record the
-// visibility value (16 B) and (meta, orig) (8 B) - goes to a per-work-group scratch in global
-// memory: it is written once and read once, coalesced, by the same CU (L2-resident), which keeps
-// LDS reads out of the accumulate loop altogether: an LDS read returns only after the wave's
-// outstanding ds_add_f64s, so every read there would drain the atomic queue.
+// Where things live (65 x 89 tiles, 15x15): LDS holds the tile (2 x 65.1 KB, resident for the whole
+// work item, flushed once) and the sort's histogram (4.1 KB).  The sorted list itself - 8 bytes per
+// record: (slice key | cell offset, orig) - goes to a per-work-group scratch in global memory: it is
+// written once and read once, coalesced, by the same CU, and the walkers gather each record's visibility
+// value from the caller's array a block of 64 records ahead of its use.  That keeps LDS reads out of the
+// accumulate loop altogether: an LDS read returns only after the wave's outstanding ds_add_f64s, so every
+// read there would drain the atomic queue.
 #include "tile_common.h"
 
 namespace gridhip {
@@ -35,8 +36,8 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // Roles.  The work-group's last wave is the SORTER: it pulls the next work item from the queues and
 // counting-sorts its records into the other half of the scratch while the remaining waves (WALKERS)
 // accumulate the current item; the accumulate loop is bound by the LDS atomic unit, which the sorter
-// barely touches, so the sort's latency chains (record load -> LDS histogram slot -> value gather ->
-// store) disappear behind it.  A work-group of one wave does both, one after the other.
+// barely touches, so the sort's latency chains (record load -> LDS histogram slot -> store) disappear
+// behind it.  A work-group of one wave does both, one after the other.
 constexpr int SORTED_IM_OFF = 65528;  // largest multiple of 8 that a DS instruction's offset field holds
 
 // piece boundaries of the 15 walkers in 1/1024ths of the sorted list.  The SIMD arbiter favours its oldest wave, so with
@@ -471,46 +472,41 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                 }
             };
 
-            // Three tap sets used in strict rotation: while run r is accumulated from one set, the
-            // taps of runs r+1 and r+2 are in flight into the other two.  The only loop exit sits
-            // after a full A+B+C trip and every set is "used" after it, so LLVM cannot sink a
-            // prefetch past the exit test; runs of length 0 pad the tail.
-            double2 kA[NSTEP], kB[NSTEP], kC[NSTEP];
-            int keyA, startA, lenA, keyB, startB, lenB, keyC, startC, lenC;
-            advance(keyA, startA, lenA);
-            issue(kA, keyA, lenA);
-            advance(keyB, startB, lenB);
-            issue(kB, keyB, lenB);
+            // NSETS tap sets used in strict rotation: while run r is accumulated from one set, the taps of runs
+            // r+1 .. r+NSETS-1 are in flight into the others.  Three sets, two runs ahead (a fourth, which the gridding
+            // instantiations have the registers for, measured no faster at 4096^2 and 1 % slower at 8192^2: what the
+            // walkers wait for there is the L2's bandwidth, not its latency).  The only loop exit sits after a full
+            // trip over the sets and every set is "used" after it, so LLVM cannot sink a prefetch past the exit test;
+            // runs of length 0 pad the tail.
+            constexpr int NSETS = 3;
+            double2 kS[NSETS][NSTEP];
+            int keyS[NSETS], startS[NSETS], lenS[NSETS];
+#pragma unroll
+            for (int r = 0; r < NSETS - 1; ++r) {
+                advance(keyS[r], startS[r], lenS[r]);
+                issue(kS[r], keyS[r], lenS[r]);
+            }
             int done = 0;
             for (;;) {
-                advance(keyC, startC, lenC);
-                issue(kC, keyC, lenC);
-                asm volatile("" ::: "memory");  // compiler fence: the prefetch may not sink below this point
-                __builtin_amdgcn_sched_barrier(0);
-                process(kA, startA, lenA);
-                __builtin_amdgcn_sched_barrier(0);
-                done += lenA;
-
-                advance(keyA, startA, lenA);
-                issue(kA, keyA, lenA);
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                process(kB, startB, lenB);
-                __builtin_amdgcn_sched_barrier(0);
-                done += lenB;
-
-                advance(keyB, startB, lenB);
-                issue(kB, keyB, lenB);
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                process(kC, startC, lenC);
-                __builtin_amdgcn_sched_barrier(0);
-                done += lenC;
+#pragma unroll
+                for (int r = 0; r < NSETS; ++r) {
+                    const int nx = (r + NSETS - 1) % NSETS;  // (compile time after unrolling)
+                    advance(keyS[nx], startS[nx], lenS[nx]);
+                    issue(kS[nx], keyS[nx], lenS[nx]);
+                    asm volatile("" ::: "memory");  // compiler fence: the prefetch may not sink below this point
+                    __builtin_amdgcn_sched_barrier(0);
+                    process(kS[r], startS[r], lenS[r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    done += lenS[r];
+                }
                 if (done >= bcnt) break;
             }
-            // The last two prefetches stay "used" on the exit path (in a branch that is never taken: done
-            // equals bcnt here), so LLVM cannot sink them below the exit test, and nothing waits for them.
-            if (done > bcnt) asm volatile("" ::"v"(kA[0].x), "v"(kA[NSTEP - 1].y), "v"(kB[0].x), "v"(kB[NSTEP - 1].y));
+            // The last prefetches stay "used" on the exit path (in a branch that is never taken: done equals bcnt
+            // here), so LLVM cannot sink them below the exit test, and nothing waits for them.
+            if (done > bcnt) {
+#pragma unroll
+                for (int r = 0; r < NSETS - 1; ++r) asm volatile("" ::"v"(kS[r][0].x), "v"(kS[r][NSTEP - 1].y));
+            }
             if (EXTRA > 0 && !(ABL & 1) && lane < bcnt) {
                 const int lb = (int)(mo.x & 0xffff);
 #pragma unroll
