@@ -130,15 +130,19 @@ def lds_atomic_cycles_per_vis(S):
 
 
 def csrc_fingerprint():
-    """sha256 over the sources of the measured kernels (pre-pass + tile kernels): a PMC measurement is only quoted
-    for the code it was taken on."""
+    """sha256 over the sources of the measured kernels (pre-pass + tile kernels), comments and white space left out:
+    a PMC measurement is only quoted for the code it was taken on."""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.startswith(("tile_", "bin", "common")) and name.endswith((".hip", ".h")):
+            src = open(os.path.join(d, name), "r", encoding="utf-8", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            src = re.sub(r"//[^\n]*", "", src)
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(re.sub(r"\s+", "", src).encode())
     return h.hexdigest()[:16]
 
 
