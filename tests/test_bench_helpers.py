@@ -52,11 +52,14 @@ def test_traffic_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path, mon
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
     os.makedirs(tmp_path / "ska-sdp-accelerate-gridding_amd" / "csrc")
-    (tmp_path / "ska-sdp-accelerate-gridding_amd" / "csrc" / "tile_k.hip").write_text("// v1\n")
+    src = tmp_path / "ska-sdp-accelerate-gridding_amd" / "csrc" / "tile_k.hip"
+    src.write_text("// v1\nint f(int x) { return x + 1; }\n")
     fp = bench.csrc_fingerprint()
     (tmp_path / "profiles" / "traffic.json").write_text(json.dumps({"cfg3": {"hbm_bytes_per_launch": 1e9, "csrc_sha16": fp}}))
     assert bench.committed_traffic("cfg3")[0] == 1e9
-    (tmp_path / "ska-sdp-accelerate-gridding_amd" / "csrc" / "tile_k.hip").write_text("// v2\n")
+    src.write_text("// another comment /* and */\nint f(int x)   {\n    return x + 1;  /* same code */\n}\n")
+    assert bench.committed_traffic("cfg3")[0] == 1e9      # comments and white space do not count
+    src.write_text("// v1\nint f(int x) { return x + 2; }\n")
     assert bench.committed_traffic("cfg3")[0] is None
     assert bench.committed_traffic("cfg2")[0] is None
 
