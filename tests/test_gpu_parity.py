@@ -144,6 +144,33 @@ def test_two_level_prepass(ctx, oracle, shape, dist, mode):
     assert np.all(d[~keep] == 0)
 
 
+@pytest.mark.parametrize("shift", [0, 1])
+def test_counting_sweep_with_and_without_16_byte_alignment(ctx, oracle, shift):
+    """The counting sweep of the two-level pre-pass reads u, v, wbin two visibilities at a time (16-byte accesses,
+    grid-stride) when the arrays are 16-byte aligned, and one at a time otherwise: device arrays that start 8 bytes
+    into an allocation take the second path.  An odd stream length exercises the first path's tail."""
+    import torch
+    N, W, Q, S, n = 256, 8, 4, 9, 150001
+    gcf, u, v, wb, vis = case(909, N, N, W, Q, S, S, n, spread=0.55)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
+    dev = torch.device("cuda:0")
+    def put(a):  # a device copy whose first element sits `shift` elements into its allocation
+        buf = torch.empty(len(a) + shift, dtype=torch.from_numpy(a[:1]).dtype, device=dev)
+        buf[shift:] = torch.from_numpy(a).to(dev)
+        return buf[shift:]
+    tu, tv, twb = put(u), put(v), put(wb)
+    assert tu.data_ptr() % 16 == 8 * shift
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    try:
+        ctx.set_option("prepass", 2)
+        ctx.convgrid2(torch.from_numpy(gcf).to(dev), G, (tu, tv, None), twb, torch.from_numpy(vis).to(dev))
+        torch.cuda.synchronize()
+        errors = ctx.get_option("errors")
+    finally:
+        ctx.set_option("prepass", 0)
+    assert errors == 0 and rel(G.cpu().numpy(), ref) < TOL
+
+
 @pytest.mark.parametrize("prepass", [1, 2])
 def test_calls_whose_record_fields_do_not_fit_are_cut_into_parts(ctx, oracle, prepass):
     """A record is one 64-bit word (14 bits of footprint origin, the kernel slice, the visibility's index); a call
