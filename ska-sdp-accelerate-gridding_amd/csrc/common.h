@@ -146,8 +146,11 @@ struct gridhip_ctx {
     bool ev_open = false;  // a call has recorded its first event and not yet its last
     uint32_t attr_mask = 0;  // pre-pass kernels whose dynamic-LDS limit has been raised
     std::unordered_set<const void *> lds_raised;  // tile kernels whose dynamic-LDS limit has been raised
-    void *fft_plan = nullptr;  // cached hipFFT Z2Z plan (imaging.hip)
-    int64_t fft_n = 0;
+    // cached hipFFT Z2Z plans (imaging.hip): do_imaging with w_cache_imaging alternates between the kernel generator's
+    // size and the image's, and creating a plan costs milliseconds
+    void *fft_plan[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t fft_n[4] = {0, 0, 0, 0};
+    int fft_next = 0;  // the slot the next new size replaces
 };
 
 namespace gridhip {

@@ -307,15 +307,21 @@ int dev_fft2c(gridhip_ctx *ctx, int64_t N, const double2 *in, double2 *out, doub
     GH_CHECK(load_hipfft(ctx));
     if (N > 0x7fffffff) return fail(ctx, GRIDHIP_EUNSUPPORTED, "fft size");
     void *plan = nullptr;
-    if (ctx->fft_plan && ctx->fft_n == N)
-        plan = ctx->fft_plan;
-    else {
-        if (ctx->fft_plan) g_fft.destroy(ctx->fft_plan);
-        ctx->fft_plan = nullptr;
+    for (int i = 0; i < 4; ++i)
+        if (ctx->fft_plan[i] && ctx->fft_n[i] == N) plan = ctx->fft_plan[i];
+    if (!plan) {
+        const int slot = ctx->fft_next;
+        if (ctx->fft_plan[slot]) {
+            // (a plan may still be in use by work queued on the stream)
+            GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            g_fft.destroy(ctx->fft_plan[slot]);
+        }
+        ctx->fft_plan[slot] = nullptr;
         int rc = g_fft.plan2d(&plan, (int)N, (int)N, 0x69 /* HIPFFT_Z2Z */);
         if (rc) return fail(ctx, GRIDHIP_EHIP, "hipfftPlan2d(%lld) failed: %d", (long long)N, rc);
-        ctx->fft_plan = plan;
-        ctx->fft_n = N;
+        ctx->fft_plan[slot] = plan;
+        ctx->fft_n[slot] = N;
+        ctx->fft_next = (slot + 1) % 4;
     }
     if (int rc = g_fft.setstream(plan, ctx->stream)) return fail(ctx, GRIDHIP_EHIP, "hipfftSetStream: %d", rc);
     hipLaunchKernelGGL(roll_kernel, grid_for(ctx, N * N), dim3(256), 0, ctx->stream, N, in, tmp, N / 2, 1.0);
@@ -329,8 +335,10 @@ int dev_fft2c(gridhip_ctx *ctx, int64_t N, const double2 *in, double2 *out, doub
 
 void fft_release(gridhip_ctx *ctx)
 {
-    if (ctx->fft_plan && g_fft.h) g_fft.destroy(ctx->fft_plan);
-    ctx->fft_plan = nullptr;
+    for (int i = 0; i < 4; ++i) {
+        if (ctx->fft_plan[i] && g_fft.h) g_fft.destroy(ctx->fft_plan[i]);
+        ctx->fft_plan[i] = nullptr;
+    }
 }
 
 // one plane of the w-kernel table: out[Q][Q][S][S] (conjugated when the caller is w_cache_imaging, :441)
