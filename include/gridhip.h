@@ -90,7 +90,8 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               bounds checks have something to reject (counted in "errors"; results are then incomplete)
  *   "wtable"    which table of walker weights the tap-reusing kernel uses: 0 = auto, 1 = flat, 2 = steep (tile_sorted.hip)
  *   "rec_bits"  TEST HOOK: pretend the 64-bit record word has this many bits (16..63), so that small calls take the
- *               path that grids a call in several parts (taken for real above 2^50 slices x visibilities)
+ *               path that grids a call in several parts (taken for real above 2^50 slices x visibilities);
+ *               100 + t: widen the record's kernel-slice field until its fields take t <= 64 bits
  *   ("dbg", the ablation / profiling switch of tuning runs, exists only in the tuning build of the library,
  *   `make -C csrc tuning` -> lib/libgridhip_tuning.so; the shipped library rejects the key)
  * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel

@@ -95,6 +95,10 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     g->px = g->py = g->P = 1;
     g->per_vis = 0;
     set_rec_bits(g);
+    // test hook: rec_bits = 100 + t widens the kslice field until the record's fields take t bits (t = 64: they fill
+    // the word exactly, as they do in every part of a call that had to be cut)
+    if (ctx->opt.rec_bits >= 100 && ctx->opt.rec_bits <= 164 && g->ob + g->kb + 14 < ctx->opt.rec_bits - 100)
+        g->kb = (int32_t)(ctx->opt.rec_bits - 100) - 14 - g->ob;
 
     const size_t lds_cap = (size_t)ctx->max_lds - 1024;
     // one plane (re or im) of the tap-reusing kernel's tile must fit below the fixed re / im distance (tile_sorted.hip)

@@ -59,7 +59,8 @@ __device__ __forceinline__ VisRec load_rec(const RecWord *__restrict__ recs, int
     r.lxy = (min(ly, g.Ty - 1) << 16) | min(lx, g.Tx - 1);
     r.kslice = min(k, g.nslices - 1);
     r.orig = min(o, g.nvis - 1);
-    if (clamped) *clamped = r.lxy != ((ly << 16) | lx) || r.kslice != k || r.orig != o || (w >> (sx + 14)) != 0;
+    // (bits above the fields must be clear; the fields may fill the word exactly, and a shift by 64 is undefined)
+    if (clamped) *clamped = r.lxy != ((ly << 16) | lx) || r.kslice != k || r.orig != o || (sx + 14 < 64 && (w >> (sx + 14)) != 0);
     return r;
 }
 

@@ -172,6 +172,30 @@ def test_counting_sweep_with_and_without_16_byte_alignment(ctx, oracle, shift):
 
 
 @pytest.mark.parametrize("prepass", [1, 2])
+def test_record_fields_that_fill_the_word_exactly(ctx, oracle, prepass):
+    """Every part of a call that had to be cut has records whose fields take all 64 bits.  The test hook
+    rec_bits = 164 widens the kernel-slice field to that point on a small case: no record may be reported as
+    inconsistent (the host-pointer forms would return GRIDHIP_EINVAL), and the 12-byte intermediate records that
+    streams without spare bits use are exercised on the way."""
+    N, W, Q, S, n = 128, 8, 4, 7, 40000
+    gcf, u, v, wb, vis = case(616, N, N, W, Q, S, S, n, spread=0.55)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
+    rng = np.random.default_rng(5)
+    G = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    dref = oracle.degrid2(gcf, G, u, v, wb)
+    try:
+        ctx.set_option("prepass", prepass)
+        ctx.set_option("rec_bits", 164)
+        got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+        d = ctx.degrid2(gcf, G, (u, v, None), wb)
+        errors = ctx.get_option("errors")
+    finally:
+        ctx.set_option("prepass", 0)
+        ctx.set_option("rec_bits", 0)
+    assert errors == 0 and rel(got, ref) < TOL and rel(d, dref) < TOL
+
+
+@pytest.mark.parametrize("prepass", [1, 2])
 def test_calls_whose_record_fields_do_not_fit_are_cut_into_parts(ctx, oracle, prepass):
     """A record is one 64-bit word (14 bits of footprint origin, the kernel slice, the visibility's index); a call
     with slices x visibilities above 2^50 is gridded / degridded in parts.  The test hook "rec_bits" pretends the
