@@ -84,6 +84,10 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               coarse bin and then per bin), 3 = one level with global atomics only (no LDS; a measured
  *               baseline), 4 = two levels recomputing from the stream instead of reading pre-records,
  *               5, 6 = two levels with 16-byte / 12-byte instead of 8-byte intermediate records
+ *   "coarse_shift", "scatter_chunk", "count_unroll"  details of that scatter kept for comparison runs: bins per
+ *               coarse bin = 2^coarse_shift (0 = balanced); scatter_chunk = 4096: half-size chunks, two work-groups
+ *               per CU; count_unroll = 4: four visibilities per thread and trip in the counting sweep, 1: one, and
+ *               no 16-byte grid-stride form either (0 = auto)
  *   "aw_cache"  aw gridders: 1 (default) = build each distinct (a1, a2, wbin, yf, xf) kernel once per call and let
  *               the visibilities that share it reuse it; 0 = one kernel per visibility (as the reference evaluates)
  *   "fault_inject"  TEST HOOK: hides the last k slots of the record array from the pre-pass's scatter so that its
