@@ -16,6 +16,13 @@ import gridhip
 sets = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")] or [""]
 wl = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--workload=")]
 n, N, W, Q, S = bench.WORKLOADS[wl[0] if wl else "cfg3"]
+for a_ in sys.argv[1:]:  # --n= / --grid= / --planes= override the workload's shape (the stamps exist for 15 x 15 only)
+    if a_.startswith("--n="):
+        n = int(float(a_[4:]))
+    if a_.startswith("--grid="):
+        N = int(a_[7:])
+    if a_.startswith("--planes="):
+        W = int(a_[9:])
 dev = torch.device("cuda:0")
 ctx = gridhip.Context(0)
 gcf = bench.synth_kernels(W, Q, S, dev)
