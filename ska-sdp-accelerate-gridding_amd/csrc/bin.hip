@@ -10,12 +10,12 @@
 // Small streams (< 2^22 visibilities) then write each record straight to its bin:
 //   bin_offsets : per-work-group histograms -> each work-group's first slot in every bin
 //   bin_scatter : a second sweep over the stream writes each visibility's record into its work-group's range
-// A record written straight to its bin is a lone 12-byte store into one of ~10^5 open regions, i.e. one
+// A record written straight to its bin is a lone 8-byte store into one of ~10^5 open regions, i.e. one
 // partial-line HBM write per visibility (2.6 ms for 10^8 records against 0.45 ms for the counting sweep), so
 // large streams scatter in two levels, both through an LDS counting sort so that records leave the CU as
 // contiguous runs (option "prepass": 0 = auto, 1 = one level, 2 = two levels, 3 = one level with global atomics
-// only, 4 = two levels recomputing from the stream instead of reading pre-records, 5 = two levels with 16-byte
-// intermediate records):
+// only, 4 = two levels recomputing from the stream instead of reading pre-records, 5 / 6 = two levels with 16- /
+// 12-byte intermediate records):
 //   coarse_scatter : chunks of 8192 pre-records are counting-sorted by COARSE bin (2^k consecutive bins) in LDS
 //                    and written as runs into a temporary array laid out like the final one at coarse
 //                    granularity (one global atomic per chunk and non-empty coarse bin reserves the run's place)

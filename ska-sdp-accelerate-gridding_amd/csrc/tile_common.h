@@ -64,9 +64,10 @@ __device__ __forceinline__ VisRec load_rec(const RecWord *__restrict__ recs, int
     return r;
 }
 
-// A 16-byte load with the non-temporal hint: the sorter's gather of visibility values, each used once (measured with
-// the records' hint: tile kernel 11.5 -> 11.3 ms, HBM traffic 34.5 -> 31.8 GB per launch, TCC hit rate 53 -> 60 %; the
-// same hint on the walkers' reads of the sorted list measured slower, on its stores 4 % slower)
+// A 16-byte load with the non-temporal hint: the gather of visibility values, each used once (measured together with
+// the records' hint when the sorter still did the gather: tile kernel 11.5 -> 11.3 ms, HBM traffic 34.5 -> 31.8 GB per
+// launch, TCC hit rate 53 -> 60 %; the same hint on the walkers' reads of the sorted list measured slower, on its
+// stores 4 % slower)
 typedef double dvec2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 load_nt(const double2 *p)
 {

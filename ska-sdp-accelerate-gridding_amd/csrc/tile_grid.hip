@@ -4,7 +4,7 @@
 // One work item = (w-group, grid tile, chunk of <=chunk binned visibilities).  A work-group
 // keeps the tile plus its kernel-support halo — (T+gh-1) x (T+gw-1) complex cells, planar
 // re/im, 35 KB at T=32 / 100 KB at T=64 for 15x15 — in LDS (160 KB per CU).  Each wave takes
-// one visibility at a time: its 16-byte record and its value arrive by broadcast loads, lanes map
+// one visibility at a time: its 8-byte record and its value arrive by broadcast loads, lanes map
 // to kernel taps (64 consecutive taps per step) so the tap read from the [gh][gw] slice is one
 // coalesced run and the accumulate is a conflict-free ds_add_f64 (row pitch chosen in ctx.hip).  The grid read-modify-write of the reference's `permute (+)`
 // therefore never leaves the CU; HBM sees the tile once, when the work-group flushes it with
