@@ -333,11 +333,17 @@ __global__ void __launch_bounds__(256) bin_offsets_kernel(int nbins, int nblocks
     const int bin = blockIdx.x * blockDim.x + threadIdx.x;
     if (bin >= nbins) return;
     int run = bin_start[bin];
-    for (int b = 0; b < nblocks; ++b) {
-        int32_t *p = block_hist + (size_t)b * nbins + bin;
-        const int c = *p;
-        *p = run;
-        run += c;
+    // (eight blocks' counts are read together: the walk is a chain of memory latencies otherwise - 16 -> 5 us at
+    // 61 work-groups, which is 6 % of a 10^6-visibility call)
+    for (int b0 = 0; b0 < nblocks; b0 += 8) {
+        int c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = b0 + q < nblocks ? block_hist[(size_t)(b0 + q) * nbins + bin] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (b0 + q < nblocks) block_hist[(size_t)(b0 + q) * nbins + bin] = run;
+            run += c[q];
+        }
     }
 }
 
