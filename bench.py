@@ -6,9 +6,15 @@
 One process per GPU.  Started under `python -m torch.distributed.run --nproc-per-node N` the ranks come from
 the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); started as a plain command with --gpus N > 1 this
 process only spawns the N rank processes (before anything touches a GPU) and relays rank 0's JSON line.
-Visibilities are sharded across ranks (weak scaling: every rank grids its own shard onto a private N x N
-complex128 grid) and the partial grids are summed with ONE RCCL fp64 all-reduce per step, issued on a side
-stream so that it overlaps the next step's gridding.
+Visibilities are sharded across ranks - ONE global, counter-based stream (visibility k's values depend on (seed, k)
+only), of which rank r grids a contiguous range onto a private N x N complex128 grid - and the partial grids are
+summed with ONE RCCL fp64 collective per step, issued on a side stream so that it overlaps the next step's gridding.
+--scaling weak (default): the stream has n_gpus x vis_per_gpu visibilities, every GPU grids vis_per_gpu of them;
+--scaling strong: the stream has the workload's visibilities in total, every GPU grids 1 / n_gpus of them (the
+N-GPU grid then equals the 1-GPU grid of the same stream).  After the timed steps every run certifies itself: the sum
+of the (reduced) grid is compared with the analytic checksum sum_k vis_k * sum_ij K[slice_k] of the stream (all taps are
+in range by construction) and the process exits non-zero if they differ by more than 1e-10 or the library counted an
+internal error.
 
 A "step" = binning pre-pass + tile kernel over the rank's whole shard (+ grid clear and all-reduce when N > 1),
 inputs already resident in HBM.  Rank 0 prints ONE JSON line.
@@ -55,9 +61,19 @@ def parse_args(argv=None):
     ap.add_argument("--dist", default="uniform", choices=["uniform", "core"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="visibilities of the CPU baseline's sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--collective", default="torch", choices=["torch", "cabi"],
-                    help="N > 1: all-reduce through torch.distributed (nccl = RCCL, overlapped with the next step) or "
-                         "through libgridhip's own RCCL communicator (gridhip_comm_*, on the gridding stream)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU grids the workload's visibilities (the stream grows with N); strong: the GPUs "
+                         "share the workload's visibilities (n / N each)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "cabi", "cabi-rs"],
+                    help="N > 1: the per-step sum of the partial grids, on a side stream beside the next step's gridding: "
+                         "torch = torch.distributed all_reduce (nccl = RCCL); cabi = libgridhip's own communicator "
+                         "(gridhip_comm_*, ncclAllReduce); cabi-rs = the same with ncclReduceScatter + ncclAllGather")
+    ap.add_argument("--reduce-rows", default="auto", choices=["auto", "all"],
+                    help="auto: the stream is mirrored (v >= 0), so only the rows it can touch are reduced (half the bytes)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="compute units the persistent tile kernel leaves free for the collective's kernel "
+                         "(-1 = auto: 16 when N > 1, else 0)")
+    ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EEDC0DE)
     ap.add_argument("--opt", action="append", default=[], help="gridhip option key=value (tile, block, chunk, wgroups, variant, sort)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per tile-kernel launch from a separate rocprofv3 --pmc pass "
@@ -201,38 +217,109 @@ def synth_akernels(A, S, device):
     return torch.polar(amp[None].expand(A, S, S).contiguous(), phase).contiguous()
 
 
-def synth_vis(n, N, W, S, seed, device, wstep=2000, dist="uniform"):
-    """Seeded synthetic stream, generated on the device in slabs."""
+# Counter-based stream: every value of visibility k is a function of (seed, k, j) only - splitmix64 of
+# seed + (8 k + j) * golden, j = the draw's number - so any rank can draw any range of the one global stream, on any
+# device, and the CPU twin (tests/test_bench_helpers.py: numpy uint64) produces the same coordinates bit for bit
+# (integer arithmetic, then exact conversions and single IEEE operations).
+_GOLD, _C1, _C2 = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+_DRAWS = 8  # counters per visibility: 0 u, 1 v, 2 w, 3 / 4 the value's Box-Muller pair, 5 / 6 "core" distribution, 7 spare
+
+
+def _s64(c):
+    """a 64-bit constant as the signed value torch's int64 arithmetic (two's complement, wrapping) holds"""
+    c &= (1 << 64) - 1
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)  # logical shift of an int64 tensor (>> is arithmetic)
+
+
+def counter_uniform(seed, k, j):
+    """U[0, 1) with 53 random bits for visibility numbers k (int64 tensor) and draw j."""
     import torch
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
+    z = (k * _DRAWS + j) * _s64(_GOLD) + _s64(seed)
+    z = (z ^ _lsr(z, 30)) * _s64(_C1)
+    z = (z ^ _lsr(z, 27)) * _s64(_C2)
+    z = z ^ _lsr(z, 31)
+    return _lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
+def counter_uniform_numpy(seed, k, j):
+    """The CPU twin of counter_uniform in numpy uint64 arithmetic (k: integer array)."""
+    import numpy as np
+    m = (1 << 64) - 1
+    with np.errstate(over="ignore"):
+        z = (np.asarray(k).astype(np.uint64) * np.uint64(_DRAWS) + np.uint64(j)) * np.uint64(_GOLD) + np.uint64(seed & m)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(_C1)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(_C2)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def synth_vis(n, N, W, S, seed, device, wstep=2000, dist="uniform", lo=0):
+    """Visibilities [lo, lo + n) of the global synthetic stream, generated on `device` in slabs."""
+    import math
+    import torch
     u = torch.empty(n, dtype=torch.float64, device=device)
     v = torch.empty(n, dtype=torch.float64, device=device)
     wb = torch.empty(n, dtype=torch.int64, device=device)
     vis = torch.empty(n, dtype=torch.complex128, device=device)
     m = (S / 2 + 1) / N  # margin so that every tap is in range
     slab = 1 << 24
-    for lo in range(0, n, slab):
-        hi = min(n, lo + slab)
-        k = hi - lo
+
+    def normal_pair(k, j):  # Box-Muller on draws j, j + 1 (1 - U is in (0, 1]: the logarithm is finite)
+        r = torch.sqrt(-2.0 * torch.log(1.0 - counter_uniform(seed, k, j)))
+        t = (2.0 * math.pi) * counter_uniform(seed, k, j + 1)
+        return r * torch.cos(t), r * torch.sin(t)
+
+    for a in range(0, n, slab):
+        b = min(n, a + slab)
+        k = torch.arange(lo + a, lo + b, dtype=torch.int64, device=device)
         if dist == "uniform":
-            pu = (torch.rand(k, generator=gen, device=device, dtype=torch.float64) - 0.5) * (1 - 2 * m)
-            pv = (torch.rand(k, generator=gen, device=device, dtype=torch.float64) - 0.5) * (1 - 2 * m)
+            pu = (counter_uniform(seed, k, 0) - 0.5) * (1 - 2 * m)
+            pv = (counter_uniform(seed, k, 1) - 0.5) * (1 - 2 * m)
         else:  # "core": centrally concentrated, contention stress
-            pu = (torch.randn(k, generator=gen, device=device, dtype=torch.float64) * 0.08).clamp(-0.5 + m, 0.5 - m)
-            pv = (torch.randn(k, generator=gen, device=device, dtype=torch.float64) * 0.08).clamp(-0.5 + m, 0.5 - m)
+            gu, gv = normal_pair(k, 5)
+            pu = (gu * 0.08).clamp(-0.5 + m, 0.5 - m)
+            pv = (gv * 0.08).clamp(-0.5 + m, 0.5 - m)
         # mirror_uvw (src/Gridding.hs:558-561): v >= 0
         neg = pv < 0
         pu = torch.where(neg, -pu, pu)
         pv = torch.where(neg, -pv, pv)
-        ww = torch.rand(k, generator=gen, device=device, dtype=torch.float64) * (W * wstep)
+        ww = counter_uniform(seed, k, 2) * (W * wstep)
         # w-bin rule of w_cache_imaging (src/Gridding.hs:426-432), clamped to the planes we have
-        b = torch.round(ww / wstep).to(torch.int64).clamp_(0, W - 1)
-        re = torch.randn(k, generator=gen, device=device, dtype=torch.float64)
-        im = torch.randn(k, generator=gen, device=device, dtype=torch.float64)
-        u[lo:hi], v[lo:hi], wb[lo:hi] = pu, pv, b
-        vis[lo:hi] = torch.complex(re, im)
+        u[a:b], v[a:b] = pu, pv
+        wb[a:b] = torch.round(ww / wstep).to(torch.int64).clamp_(0, W - 1)
+        re, im = normal_pair(k, 3)
+        vis[a:b] = torch.complex(re, im)
     return u, v, wb, vis
+
+
+def expected_checksum(u, v, wb, vis, gcf, N):
+    """sum(G) a correct convgrid2 of this stream produces when every tap is in range: sum_k vis_k * sum_ij K[slice_k],
+    with the slice index recomputed from frac_coord's formula (src/Gridding.hs:126-140) in torch fp64; and the
+    absolute-value scale sum_k |vis_k| * sum_ij |K[slice_k]| the difference is judged against.  Slabs: no
+    stream-sized temporaries survive."""
+    import torch
+    W, Q = gcf.shape[0], gcf.shape[1]
+    ksum = gcf.sum(dim=(3, 4)).reshape(-1)
+    kabs = gcf.abs().sum(dim=(3, 4)).reshape(-1)
+    tot = torch.zeros((), dtype=torch.complex128, device=u.device)
+    scale = torch.zeros((), dtype=torch.float64, device=u.device)
+
+    def frac(p):
+        x = N // 2 + p * N
+        fl = torch.floor(x + 0.5 / Q)
+        return torch.round((x - fl) * Q).clamp_(0, Q - 1).to(torch.int64)
+
+    slab = 1 << 24
+    for a in range(0, u.shape[0], slab):
+        b = min(u.shape[0], a + slab)
+        idx = (wb[a:b] * Q + frac(v[a:b])) * Q + frac(u[a:b])
+        tot += (vis[a:b] * ksum[idx]).sum()
+        scale += (vis[a:b].abs() * kabs[idx]).sum()
+    return tot, scale
 
 
 def synth_aw_stream(n, N, W, S, A, seed, device, dumps=8, drift_cells=0.02, wstep=2000):
@@ -266,9 +353,10 @@ def synth_aw_stream(n, N, W, S, A, seed, device, dumps=8, drift_cells=0.02, wste
 
 
 # ---------------------------------------------------------------------------------------------------------
-def cpu_baseline(u, v, wb, vis, gcf, N, n, sample_override):
+def cpu_baseline(ctx, u, v, wb, vis, gcf, N, n, sample_override):
     """Time the CPU oracle (C/OpenMP restatement of src/Gridding.hs:199-244, NOT Accelerate) on a bounded sample,
-    all three of its threading modes; `value` is the best of them."""
+    all three of its threading modes; `value` is the best of them.  The oracle's grid of the largest sample is then
+    also the checker of the GPU's grid of the same sample, cell by cell (`parity_rel_err`)."""
     import numpy as np
     from oracle import gridref_c
     gridref_c.build()
@@ -277,6 +365,7 @@ def cpu_baseline(u, v, wb, vis, gcf, N, n, sample_override):
     names = {0: "shared grid + atomic updates (what a parallel permute (+) does)", 1: "private grids + reduction",
              2: "owner computes: bands of grid rows, one thread each"}
     modes = {}
+    parity = None
     for mode in (2, 1, 0):
         sample = sample_override or (40_000_000 if mode == 2 else 4_000_000)
         sample = min(sample, n)
@@ -289,6 +378,13 @@ def cpu_baseline(u, v, wb, vis, gcf, N, n, sample_override):
         gridref_c.convgrid2(hk, G, hu, hv, hw, hvis, mt_mode=mode, nthreads=threads)
         dt = time.perf_counter() - t0
         modes[names[mode]] = {"Mvis_per_s": sample / dt / 1e6, "sample_vis": sample, "seconds": dt, "threads": threads}
+        if mode == 2:  # the GPU's grid of the same visibilities against it
+            import torch
+            Gd = torch.zeros((N, N), dtype=torch.complex128, device=u.device)
+            ctx.convgrid2(gcf, Gd, (u[:sample], v[:sample], None), wb[:sample], vis[:sample])
+            ref = torch.from_numpy(G).to(u.device)
+            parity = {"rel_err": float(((Gd - ref).abs().max() / ref.abs().max()).item()), "sample_vis": sample}
+            del Gd, ref
     best = max(modes, key=lambda k: modes[k]["Mvis_per_s"])
     return {
         "value": modes[best]["Mvis_per_s"],
@@ -300,11 +396,15 @@ def cpu_baseline(u, v, wb, vis, gcf, N, n, sample_override):
                   f"(oracle/gridref.c, restatement of src/Gridding.hs:199-244; the Accelerate llvm-native path cannot be "
                   f"built), mode '{best}', {modes[best]['seconds']:.2f} s",
         "modes": modes,
+        "parity_rel_err": parity["rel_err"] if parity else None,
+        "parity_note": (f"max |G_gpu - G_oracle| / max |G_oracle| over all cells, both gridding the first {parity['sample_vis']} "
+                        "visibilities of the workload (tolerance 1e-10)") if parity else None,
     }
 
 
-def cpu_baseline_aw(u, v, wb, a1, a2, vis, wk, ak, N, sample):
+def cpu_baseline_aw(ctx, u, v, wb, a1, a2, vis, wk, ak, N, sample):
     import numpy as np
+    import torch
     from oracle import gridref_c
     gridref_c.build()
     f = lambda t: t[:sample].cpu().numpy()
@@ -312,7 +412,14 @@ def cpu_baseline_aw(u, v, wb, a1, a2, vis, wk, ak, N, sample):
     t0 = time.perf_counter()
     gridref_c.awgrid(wk.cpu().numpy(), ak.cpu().numpy(), G, f(u), f(v), f(wb), f(a1), f(a2), f(vis))
     dt = time.perf_counter() - t0
+    g = lambda t: t[:sample]
+    Gd = torch.zeros((N, N), dtype=torch.complex128, device=u.device)
+    ctx.convgrid4(wk, ak, Gd, (g(u), g(v), None), (g(wb), g(a1), g(a2)), g(vis))
+    ref = torch.from_numpy(G).to(u.device)
+    perr = float(((Gd - ref).abs().max() / ref.abs().max()).item())
     return {"value": sample / dt / 1e6, "unit": "Mvis/s", "cores": 1, "cpu_model": cpu_model(), "kind": "port",
+            "parity_rel_err": perr,
+            "parity_note": f"max |G_gpu - G_oracle| / max |G_oracle|, both gridding the first {sample} visibilities (tolerance 1e-10)",
             "sample": f"first {sample} visibilities of the same workload, C oracle of convgrid4 (oracle/gridref.c, "
                       f"FFT-free restatement of src/Gridding.hs:318-396,761-811), single thread, {dt:.2f} s"}
 
@@ -363,50 +470,71 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import gridhip
+    from gridhip.distributed import Comm, OverlappedCommReducer, OverlappedGridReducer, mirrored_first_row, shard_bounds
     n, N, W, Q, S = WORKLOADS[args.workload]
     if args.nvis:
         n = args.nvis
     aw = args.workload == "cfg4"
+    # the one global stream and this rank's range of it
+    if args.scaling == "strong":
+        n_total = n
+        lo, hi = shard_bounds(n_total, world, rank)
+    else:
+        n_total = n * world
+        lo, hi = rank * n, (rank + 1) * n
+    n_rank = hi - lo
+    n = n_rank  # visibilities per launch on this rank: what the per-kernel figures below are per
     ctx = gridhip.Context(local_rank)
     for kv in args.opt:
         k, val = kv.split("=")
         ctx.set_option(k, int(val))
     if aw:
         ctx.set_option("aw_cache", args.aw_cache)
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (16 if world > 1 else 0)
+    if reserve:
+        ctx.set_option("reserve_cus", reserve)
 
     gcf = synth_kernels(W, Q, S, device)
     if aw:
         akerns = synth_akernels(AW_ANTENNAS, S, device)
-        u, v, wb, a1, a2, vis = synth_aw_stream(n, N, W, S, AW_ANTENNAS, 0x5EEDC0DE + rank, device)
+        u, v, wb, a1, a2, vis = synth_aw_stream(n_rank, N, W, S, AW_ANTENNAS, args.seed + rank, device)
     else:
-        u, v, wb, vis = synth_vis(n, N, W, S, 0x5EEDC0DE + rank, device, dist=args.dist)
-    G = torch.zeros((N, N), dtype=torch.complex128, device=device)
-    from gridhip.distributed import Comm, OverlappedGridReducer
-    # N > 1: one fp64 sum all-reduce of the partial grids per step over xGMI (RCCL).  "torch": issued on a side
-    # stream so that it overlaps the next step's gridding (two grid buffers used alternately); "cabi": libgridhip's
-    # own communicator, on the gridding stream.
+        u, v, wb, vis = synth_vis(n_rank, N, W, S, args.seed, device, dist=args.dist, lo=lo)
+    # N = 1: every step grids onto a grid that was zeroed BEFORE the timed region ("grid re-zeroed outside
+    # the timed region") - a ring of zeroed grids, one per step (more steps than grids: the ring wraps and a grid
+    # receives several whole passes, which the check below accounts for).
+    # N > 1: two buffers used alternately; a step clears its buffer (each step reduces its own partial grids).
+    nbuf = 2 if dist is not None else max(1, min(args.steps + args.warmup, 16))
+    bufs = [torch.zeros((N, N), dtype=torch.complex128, device=device) for _ in range(nbuf)]
+    passes = [0] * nbuf
+    G = bufs[0]
+    # N > 1: one fp64 sum of the partial grids per step over xGMI (RCCL), issued on a side stream so that it overlaps
+    # the next step's gridding.  The stream is mirrored (v >= 0): rows the footprints cannot reach stay exactly zero
+    # and are left out of the collective.
+    rows = (mirrored_first_row(N, S), N) if (args.reduce_rows == "auto" and not aw) else None
     red = comm = None
     if dist is not None:
         if args.collective == "torch":
-            red = OverlappedGridReducer([G, torch.zeros_like(G)])
+            red = OverlappedGridReducer(bufs, rows=rows)
         else:
             comm = Comm.from_torch(ctx)
+            comm.set_option("collective", 1 if args.collective == "cabi-rs" else 0)
+            red = OverlappedCommReducer(comm, bufs, rows=rows)
     counter = [0]
 
     def step():
         i = counter[0]
         counter[0] += 1
-        g = red.begin(i) if red else G  # (N > 1: the buffer is cleared, each step reduces its own partial grids)
-        if comm:
-            g.zero_()
+        g = red.begin(i) if red else bufs[i % nbuf]
+        if red:
+            passes[i % 2] = 0
+        passes[i % nbuf] += 1
         if aw:
             ctx.convgrid4(gcf, akerns, g, (u, v, None), (wb, a1, a2), vis)
         else:
-            ctx.convgrid2(gcf, g, (u, v, None), wb, vis)  # this rank's shard (generated per rank)
+            ctx.convgrid2(gcf, g, (u, v, None), wb, vis)  # this rank's range of the stream
         if red:
             red.end(i)
-        if comm:
-            comm.allreduce_grid(g)
 
     ctx.enable_timing(True)
     for _ in range(args.warmup):
@@ -438,31 +566,80 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([float(errors)], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        errors = int(t.item())
+
+    # ---- the run certifies itself (outside the timed region): the sum of every grid the steps produced against the
+    # analytic checksum of the stream.  N > 1: the reduced grids hold the contributions of ALL ranks (rows the
+    # collective skipped must then be zero on every rank, or the sums disagree), so the expected value is all-reduced.
+    check = None
+    if not aw:
+        tc0 = time.perf_counter()
+        expect, scale = expected_checksum(u, v, wb, vis, gcf, N)
+        ex = torch.stack([expect.real, expect.imag, scale])
+        if dist is not None:
+            dist.all_reduce(ex)
+        expect, scale = complex(ex[0].item(), ex[1].item()), ex[2].item()
+        worst, nonzero = 0.0, 0
+        for b, g in enumerate(bufs):
+            if passes[b] == 0:
+                continue
+            got = complex(g.sum().item())
+            worst = max(worst, abs(got - passes[b] * expect) / (passes[b] * scale))
+            nonzero = max(nonzero, int((g != 0).sum().item()))
+        if dist is not None:
+            t = torch.tensor([worst], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = float(t.item())
+        torch.cuda.synchronize()
+        check = {"rel_err": worst, "tolerance": 1e-10, "cells_nonzero": nonzero, "grids_checked": sum(1 for x in passes if x),
+                 "what": "max over the grids the timed and warm-up steps produced of |sum(G) - passes * sum_k vis_k * "
+                         "sum_ij K[slice_k]| / (passes * sum_k |vis_k| * sum_ij |K[slice_k]|); slices recomputed from "
+                         "frac_coord's formula in torch; N > 1: G is the reduced grid, the expectation is summed over ranks",
+                 "seconds": time.perf_counter() - tc0}
 
     # N > 1: what the collective costs on its own (outside the timed region; gridding and all-reduce separately)
     multi = None
     if dist is not None:
-        tg = torch.view_as_real(G)
+        part = G if rows is None else G[rows[0]:rows[1]]
+        tg = torch.view_as_real(part)
+
+        def one():
+            if args.collective == "torch":
+                dist.all_reduce(tg)
+            elif rows is None:
+                comm.allreduce_grid(G)
+            else:
+                comm.allreduce_grid_rows(G, *rows)
+
+        if comm:
+            red.close()  # (the communicator's collectives go back to the context's stream = torch's current stream)
+            ctx._use_torch_stream()
         for _ in range(2):
-            dist.all_reduce(tg)
+            one()
         torch.cuda.synchronize()
         dist.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            dist.all_reduce(tg)
+            one()
         e1.record()
         torch.cuda.synchronize()
         ar_ms = e0.elapsed_time(e1) / 5
-        multi = {"rccl_ranks": dist.get_world_size(), "collective": args.collective,
-                 "allreduce_bytes": int(G.numel() * 16), "allreduce_ms_alone": ar_ms,
-                 "allreduce_busbw_GBps": G.numel() * 16 * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9 if world > 1 else None,
+        nbytes = int(part.numel() * 16)
+        multi = {"rccl_ranks": dist.get_world_size(), "collective": args.collective, "scaling": args.scaling,
+                 "reduced_rows": list(rows) if rows else [0, N], "reserve_cus": reserve,
+                 "allreduce_bytes": nbytes, "allreduce_ms_alone": ar_ms,
+                 "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9 if world > 1 else None,
                  "gridding_ms_per_step": float(np.mean(ker_ms) + np.mean(pre_ms)),
-                 "combined_ms_per_step": elapsed / args.steps * 1e3}
+                 "combined_ms_per_step": elapsed / args.steps * 1e3,
+                 "check_rel_err": check["rel_err"] if check else None}
 
+    failed = []
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        total_vis = n * world
+        total_vis = n_total
         k_avg = float(np.mean(ker_ms))
         props = torch.cuda.get_device_properties(device)
         cus = props.multi_processor_count
@@ -485,7 +662,7 @@ def main():
                     "flops_per_launch": flops, "kernel_ms_avg": build_ms, "build_ms": stats(pre_ms),
                     "grid_ms": stats(ker_ms), "aw_cache": args.aw_cache, "aw": info}
             metric = "Mvis/s gridded (aw-proj, 4096^2 grid)"
-            what = f"aw-projection grid (convgrid4): {n} vis/GPU, {N}^2 grid, {W} w-planes, {AW_ANTENNAS} antennas, {S}x{S} support, Q={Q}"
+            what = f"aw-projection grid (convgrid4): {n_rank} vis/GPU, {N}^2 grid, {W} w-planes, {AW_ANTENNAS} antennas, {S}x{S} support, Q={Q}"
         else:
             clk = clock_ghz if clock_ghz > 0.5 else nominal_ghz
             lds_bytes = 2.0 * S * S * 8.0 * n  # operand bytes of the LDS atomics one launch needs (re + im per tap)
@@ -493,7 +670,7 @@ def main():
             peak = cus * LDS_ATOMIC_B_PER_CLK * clk  # GB/s at the clock the kernel held
             floor_ms = n * lds_atomic_cycles_per_vis(S) / cus / (clk * 1e9) * 1e3
             traffic, traffic_src = (args.traffic_bytes, "--traffic-bytes") if args.traffic_bytes else (None, None)
-            if traffic is None and not args.opt and not args.nvis and args.dist == "uniform":
+            if traffic is None and not args.opt and not args.nvis and args.dist == "uniform" and n == WORKLOADS[args.workload][0] and not reserve:
                 traffic, traffic_src = committed_traffic(args.workload)
             bmin = compulsory_bytes_per_vis(n, N, W, Q, S)
             alg = alg_bytes_per_vis(S) * n / (k_avg * 1e-3) / 1e9
@@ -523,7 +700,7 @@ def main():
                 "hbm": hbm,
             }
             metric = "Mvis/s gridded (w-proj, 4096^2 grid)" if N == 4096 else f"Mvis/s gridded (w-proj, {N}^2 grid)"
-            what = f"w-projection grid (convgrid2): {n} vis/GPU, {N}^2 grid, {W} w-planes, {S}x{S} support, Q={Q}, {args.dist} uv"
+            what = f"w-projection grid (convgrid2): {n_rank} vis/GPU, {N}^2 grid, {W} w-planes, {S}x{S} support, Q={Q}, {args.dist} uv"
         for key in ("frac", "lds_floor_frac"):
             if key in roof:
                 assert 0.0 < roof[key] <= 1.0, f"roofline.{key} = {roof[key]} is not a fraction"
@@ -537,36 +714,50 @@ def main():
             "ms_per_step": ms_per_step,
             "step_ms_device": stats([a + b for a, b in zip(ker_ms, pre_ms)]),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": what,
                 "name": args.workload,
-                "vis_per_gpu": n, "grid": N, "w_planes": W, "support": S, "oversample": Q,
-                "parallelism": f"vis-sharded x{world}" + (" + RCCL fp64 grid all-reduce per step" +
-                                                          (" (overlapped with the next step's gridding)" if red else " (libgridhip communicator)")
+                "vis_per_gpu": n_rank, "vis_total": n_total, "scaling": args.scaling, "seed": args.seed, "grid": N, "w_planes": W, "support": S, "oversample": Q,
+                "parallelism": f"vis-sharded x{world}" + (f" + RCCL fp64 grid sum per step ({args.collective}; side stream, "
+                                                          f"overlapped with the next step's gridding; {reserve} CUs reserved)"
                                                           if world > 1 else ""),
-                "scaling_note": "weak: every GPU grids its own vis_per_gpu visibilities; value = n_gpus x vis_per_gpu / step time",
+                "scaling_note": ("weak: one global counter-based stream of n_gpus x vis_per_gpu visibilities, rank r grids "
+                                 "[r, r + 1) x vis_per_gpu of it; value = vis_total / step time" if args.scaling == "weak" else
+                                 "strong: one global counter-based stream of vis_total visibilities, rank r grids its 1 / n_gpus "
+                                 "share; value = vis_total / step time"),
                 "options": opts,
             },
             "errors": errors,
+            "check": check,
             "roofline": roof,
         }
         if multi:
             out["multi_gpu"] = multi
         if world == 1 and not args.no_cpu:
             if aw:
-                out["cpu_baseline"] = cpu_baseline_aw(u, v, wb, a1, a2, vis, gcf, akerns, N, min(args.cpu_sample or 20_000, n))
+                out["cpu_baseline"] = cpu_baseline_aw(ctx, u, v, wb, a1, a2, vis, gcf, akerns, N, min(args.cpu_sample or 20_000, n))
             else:
-                out["cpu_baseline"] = cpu_baseline(u, v, wb, vis, gcf, N, n, args.cpu_sample)
+                out["cpu_baseline"] = cpu_baseline(ctx, u, v, wb, vis, gcf, N, n, args.cpu_sample)
+            pe = out["cpu_baseline"].get("parity_rel_err")
+            if pe is not None and not pe <= 1e-10:
+                failed.append(f"GPU grid of the CPU baseline's sample differs from the oracle's: {pe:.3e}")
         print(json.dumps(out), flush=True)
+    if errors:
+        failed.append(f"the library counted {errors} internal consistency errors")
+    if check is not None and not check["rel_err"] <= check["tolerance"]:
+        failed.append(f"checksum of the gridded stream is off by {check['rel_err']:.3e} (relative)")
     if comm:
         comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        print("bench.py: RESULT CHECK FAILED: " + "; ".join(failed), file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -66,6 +66,10 @@ const char *gridhip_last_error(const gridhip_ctx *ctx);
  * kernels and copies, and those run on the null stream unless the caller created another.
  * gridhip_reset_stream() goes back to the context's private non-blocking stream (which does not
  * synchronise with the null stream: only use it when the inputs are known to be complete). */
+/* A context has ONE set of scratch buffers (records, tables, sorted lists, padded kernels): when the stream changes,
+ * the new stream is made to wait (event) for what was enqueued on the old one, so a caller that alternates streams
+ * between calls cannot have one call overwrite scratch another is still reading.  (Not while either stream is being
+ * captured into a graph: a capture must not depend on work outside it - use one stream per context there.) */
 int gridhip_set_stream(gridhip_ctx *ctx, void *hip_stream);
 int gridhip_reset_stream(gridhip_ctx *ctx);
 void *gridhip_get_stream(gridhip_ctx *ctx);
@@ -92,6 +96,10 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               the visibilities that share it reuse it; 0 = one kernel per visibility (as the reference evaluates)
  *   "fault_inject"  TEST HOOK: hides the last k slots of the record array from the pre-pass's scatter so that its
  *               bounds checks have something to reject (counted in "errors"; results are then incomplete)
+ *   "reserve_cus"  compute units the persistent tile kernel leaves free (0 = none): it launches one work-group per
+ *               remaining CU, so that a collective queued on another stream (RCCL's kernel, a copy) finds CUs to start
+ *               on while the tile kernel runs instead of waiting ~10 ms for it to end; costs the tile kernel
+ *               k / num_cu of its throughput (profiles/r03_reserve_cus.txt)
  *   "wtable"    which table of walker weights the tap-reusing kernel uses: 0 = auto, 1 = flat, 2 = steep (tile_sorted.hip)
  *   "rec_bits"  TEST HOOK: pretend the 64-bit record word has this many bits (16..63), so that small calls take the
  *               path that grids a call in several parts (taken for real above 2^50 slices x visibilities);
@@ -255,10 +263,34 @@ gridhip_ctx *gridhip_comm_ctx(gridhip_comm *comm, int i);
  * `cells` complex cells each); enqueued on each context's stream, asynchronous to the host. */
 int gridhip_comm_allreduce_grids(gridhip_comm *comm, int64_t cells, double *const *grids);
 int gridhip_comm_allreduce_grid(gridhip_comm *comm, int64_t cells, double *grid); /* rank form */
+/* The same for rows [y0, y1) of grids of Wd columns only.  A stream that went through mirror_uvw (src/Gridding.hs:551-562:
+ * v >= 0) leaves every row below H/2 - gh/2 - 1 of every partial grid exactly zero; reducing from that row on halves the
+ * bytes that cross xGMI.  (Rows outside the range keep each device's own partial content.) */
+int gridhip_comm_allreduce_rows(gridhip_comm *comm, int64_t Wd, int64_t y0, int64_t y1, double *const *grids);
+int gridhip_comm_allreduce_grid_rows(gridhip_comm *comm, int64_t Wd, int64_t y0, int64_t y1, double *grid); /* rank form */
+/* Communicator options:
+ *   "collective"  0 (default) = one ncclAllReduce; 1 = ncclReduceScatter + ncclAllGather, both in place (rank r owns
+ *                 the r-th of nranks equal chunks; the remainder goes through a small all-reduce): the direct schedule
+ *                 on xGMI's point-to-point links - every GPU exchanges one chunk with each peer at once */
+int gridhip_comm_set_option(gridhip_comm *comm, const char *key, int64_t value);
+int gridhip_comm_get_option(gridhip_comm *comm, const char *key, int64_t *value);
+/* The hipStream_t device i's collectives are enqueued on.  Default: the context's own stream, i.e. ordered after its
+ * gridding calls and before the next one.  A host that wants step i's all-reduce to run beside step i+1's gridding
+ * passes a side stream here and orders the two itself (an event recorded after the gridding, waited for by the side
+ * stream; python/gridhip/distributed.py: OverlappedCommReducer), together with the context option "reserve_cus" so
+ * that the persistent tile kernel leaves the collective's kernel compute units to run on.
+ * gridhip_comm_convgrid2 (synchronous) always reduces on the gridding streams. */
+int gridhip_comm_set_stream(gridhip_comm *comm, int i, void *hip_stream);
+int gridhip_comm_reset_stream(gridhip_comm *comm, int i);
 /* convgrid2 over the communicator, host pointers, synchronous (the drop-in form).  Single-process form: the n
  * visibilities are cut into contiguous shards, one per device, gridded concurrently, the partial grids all-reduced
  * and `grid` (accumulated into) returned.  Rank form: every process passes its own shard; the incoming grid is
- * summed over ranks too, so it should be non-zero on one rank only. */
+ * summed over ranks too, so it should be non-zero on one rank only.
+ * Failures: a device whose shard fails locally still takes part in the all-reduce (the other devices / ranks would
+ * wait in it for ever otherwise) and the call then returns that device's error with `grid` untouched; the internal
+ * consistency counter ("errors") of every local device is checked before the grid is handed back.  In the rank form
+ * both are LOCAL verdicts: the other ranks have summed this rank's incomplete grid and return GRIDHIP_OK, so the host
+ * must agree on the outcome across ranks before it uses the result. */
 int gridhip_comm_convgrid2(gridhip_comm *comm, int64_t H, int64_t Wd, double *grid, int64_t n, int64_t W,
                            int64_t Q, int64_t gh, int64_t gw, const double *gcf, const double *u,
                            const double *v, int64_t uv_stride, const int64_t *wbin, const double *vis);

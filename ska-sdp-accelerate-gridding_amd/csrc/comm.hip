@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,31 +31,38 @@ struct gridhip_comm {
     bool own_ctx = false;            // single-process form: the contexts belong to the communicator
     std::vector<gridhip_ctx *> ctx;  // this process's devices
     std::vector<ncclComm_t> comms;
+    // where device i's collectives are enqueued: its context's stream (the gridding stream: ordered after the
+    // gridding calls, no overlap) unless the host has set another one (gridhip_comm_set_stream: a side stream whose
+    // collective runs beside the next step's gridding - the host orders the two with events)
+    std::vector<hipStream_t> cstream;
+    std::vector<char> has_cstream;
+    int collective = 0;              // 0 = ncclAllReduce, 1 = ncclReduceScatter + ncclAllGather (option "collective")
     std::string err;
+    hipStream_t stream_of(size_t i) const { return has_cstream[i] ? cstream[i] : ctx[i]->stream; }
 };
 
 namespace {
 
 struct Rccl {
     void *h = nullptr;
-    bool tried = false;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *);
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*GroupStart)();
     ncclResult_t (*GroupEnd)();
     const char *(*GetErrorString)(ncclResult_t);
 } g_rccl;
 
-std::string g_comm_err;  // failures before a communicator exists
+std::string g_comm_err;  // failures before a communicator exists (written under g_err_mu)
+std::mutex g_err_mu;
+std::once_flag g_rccl_once;
 
-bool load_rccl()
+bool load_rccl_once()
 {
-    if (g_rccl.h) return true;
-    if (g_rccl.tried) return false;
-    g_rccl.tried = true;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
     for (const char *nm : names)
@@ -75,6 +83,8 @@ bool load_rccl()
     GH_SYM(CommInitAll, "ncclCommInitAll")
     GH_SYM(CommDestroy, "ncclCommDestroy")
     GH_SYM(AllReduce, "ncclAllReduce")
+    GH_SYM(ReduceScatter, "ncclReduceScatter")
+    GH_SYM(AllGather, "ncclAllGather")
     GH_SYM(GroupStart, "ncclGroupStart")
     GH_SYM(GroupEnd, "ncclGroupEnd")
     GH_SYM(GetErrorString, "ncclGetErrorString")
@@ -83,9 +93,24 @@ bool load_rccl()
     return true;
 }
 
+// (several host threads may create their communicators at once: the library is loaded by exactly one of them)
+bool load_rccl()
+{
+    std::call_once(g_rccl_once, [] {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        (void)load_rccl_once();
+    });
+    return g_rccl.h != nullptr;
+}
+
 int comm_fail(gridhip_comm *c, int code, const std::string &msg)
 {
-    (c ? c->err : g_comm_err) = msg;
+    if (c)
+        c->err = msg;
+    else {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        g_comm_err = msg;
+    }
     return code;
 }
 
@@ -131,6 +156,8 @@ int gridhip_comm_create(int ndev, const int *dev_ids, gridhip_comm **out)
         c->ctx.push_back(x);
     }
     c->comms.assign(ndev, nullptr);
+    c->cstream.assign(ndev, nullptr);
+    c->has_cstream.assign(ndev, 0);
     const ncclResult_t r = g_rccl.CommInitAll(c->comms.data(), ndev, ids.data());
     if (r != ncclSuccess) {
         c->comms.clear();
@@ -165,6 +192,8 @@ int gridhip_comm_create_rank(gridhip_ctx *ctx, int nranks, int rank, const void 
     c->nranks = nranks;
     c->rank0 = rank;
     c->ctx.push_back(ctx);
+    c->cstream.assign(1, nullptr);
+    c->has_cstream.assign(1, 0);
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     ncclComm_t nc = nullptr;
@@ -185,6 +214,7 @@ int gridhip_comm_destroy(gridhip_comm *c)
         if (i < c->ctx.size() && c->ctx[i]) {
             (void)hipSetDevice(c->ctx[i]->device);
             (void)hipStreamSynchronize(c->ctx[i]->stream);
+            if (i < c->has_cstream.size() && c->has_cstream[i]) (void)hipStreamSynchronize(c->cstream[i]);
         }
         if (c->comms[i]) (void)g_rccl.CommDestroy(c->comms[i]);
     }
@@ -198,27 +228,68 @@ int gridhip_comm_ndev(const gridhip_comm *c) { return c ? (int)c->ctx.size() : 0
 int gridhip_comm_nranks(const gridhip_comm *c) { return c ? c->nranks : 0; }
 gridhip_ctx *gridhip_comm_ctx(gridhip_comm *c, int i) { return (c && i >= 0 && i < (int)c->ctx.size()) ? c->ctx[i] : nullptr; }
 
+// In-place sum over the communicator of `count` doubles at bufs[i] on this process's i-th device, enqueued on that
+// device's collective stream.  collective = 0: one ncclAllReduce (RCCL picks ring / tree).  collective = 1:
+// ncclReduceScatter + ncclAllGather, both in place - rank r owns doubles [r * chunk, (r + 1) * chunk) - which on
+// xGMI's point-to-point links is the direct schedule: every GPU exchanges one chunk with each of its 7 peers at once
+// instead of passing 2 (p - 1) / p of the buffer round a ring; what `count` leaves over after the
+// nranks equal chunks goes through a small all-reduce in the first group.
+static int comm_sum_doubles(gridhip_comm *c, size_t count, double *const *bufs)
+{
+    const size_t nd = c->ctx.size();
+    if (count == 0) return GRIDHIP_OK;
+    if (c->collective == 0 || count < (size_t)c->nranks) {
+        GH_NCCL(c, g_rccl.GroupStart());
+        for (size_t i = 0; i < nd; ++i) {
+            (void)hipSetDevice(c->ctx[i]->device);  // (one thread drives several devices: each call is made on its own)
+            const ncclResult_t r = g_rccl.AllReduce(bufs[i], bufs[i], count, ncclDouble, ncclSum, c->comms[i], c->stream_of(i));
+            if (r != ncclSuccess) {
+                (void)g_rccl.GroupEnd();
+                return comm_fail(c, GRIDHIP_EHIP, std::string("ncclAllReduce failed: ") + g_rccl.GetErrorString(r));
+            }
+        }
+        GH_NCCL(c, g_rccl.GroupEnd());
+        return GRIDHIP_OK;
+    }
+    const size_t chunk = count / (size_t)c->nranks, rem = count - chunk * (size_t)c->nranks;
+    GH_NCCL(c, g_rccl.GroupStart());
+    for (size_t i = 0; i < nd; ++i) {
+        (void)hipSetDevice(c->ctx[i]->device);
+        double *p = bufs[i];
+        const size_t r = (size_t)c->rank0 + i;
+        ncclResult_t e = g_rccl.ReduceScatter(p, p + r * chunk, chunk, ncclDouble, ncclSum, c->comms[i], c->stream_of(i));
+        if (e == ncclSuccess && rem)
+            e = g_rccl.AllReduce(p + chunk * c->nranks, p + chunk * c->nranks, rem, ncclDouble, ncclSum, c->comms[i], c->stream_of(i));
+        if (e != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return comm_fail(c, GRIDHIP_EHIP, std::string("ncclReduceScatter failed: ") + g_rccl.GetErrorString(e));
+        }
+    }
+    GH_NCCL(c, g_rccl.GroupEnd());
+    GH_NCCL(c, g_rccl.GroupStart());
+    for (size_t i = 0; i < nd; ++i) {
+        (void)hipSetDevice(c->ctx[i]->device);
+        double *p = bufs[i];
+        const size_t r = (size_t)c->rank0 + i;
+        const ncclResult_t e = g_rccl.AllGather(p + r * chunk, p, chunk, ncclDouble, c->comms[i], c->stream_of(i));
+        if (e != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return comm_fail(c, GRIDHIP_EHIP, std::string("ncclAllGather failed: ") + g_rccl.GetErrorString(e));
+        }
+    }
+    GH_NCCL(c, g_rccl.GroupEnd());
+    return GRIDHIP_OK;
+}
+
 // grids[i]: device pointer on this process's i-th device, `cells` complex cells; summed in place over
-// all devices of the communicator.  Enqueued on each context's stream (ordered after that context's
-// gridding calls, asynchronous to the host).
+// all devices of the communicator.  Enqueued on each device's collective stream (the context's own stream unless
+// gridhip_comm_set_stream chose another), asynchronous to the host.
 int gridhip_comm_allreduce_grids(gridhip_comm *c, int64_t cells, double *const *grids)
 {
     if (!c || !grids || cells < 0) return GRIDHIP_EINVAL;
     for (size_t i = 0; i < c->ctx.size(); ++i)
         if (!grids[i] && cells > 0) return comm_fail(c, GRIDHIP_EINVAL, "null grid pointer");
-    if (cells == 0) return GRIDHIP_OK;
-    GH_NCCL(c, g_rccl.GroupStart());
-    for (size_t i = 0; i < c->ctx.size(); ++i) {
-        (void)hipSetDevice(c->ctx[i]->device);  // (one thread drives several devices: each call is made on its own)
-        const ncclResult_t r = g_rccl.AllReduce(grids[i], grids[i], (size_t)cells * 2, ncclDouble, ncclSum, c->comms[i],
-                                                c->ctx[i]->stream);
-        if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            return comm_fail(c, GRIDHIP_EHIP, std::string("ncclAllReduce failed: ") + g_rccl.GetErrorString(r));
-        }
-    }
-    GH_NCCL(c, g_rccl.GroupEnd());
-    return GRIDHIP_OK;
+    return comm_sum_doubles(c, (size_t)cells * 2, grids);
 }
 
 int gridhip_comm_allreduce_grid(gridhip_comm *c, int64_t cells, double *grid)
@@ -226,6 +297,64 @@ int gridhip_comm_allreduce_grid(gridhip_comm *c, int64_t cells, double *grid)
     if (!c || c->ctx.size() != 1) return comm_fail(c, GRIDHIP_EINVAL, "rank form only: this communicator drives several devices");
     double *g[1] = {grid};
     return gridhip_comm_allreduce_grids(c, cells, g);
+}
+
+// Rows [y0, y1) of grids of Wd columns only.  A stream that went through mirror_uvw (src/Gridding.hs:551-562:
+// v >= 0) leaves every row below H / 2 - gh / 2 - 1 of every partial grid exactly zero, and summing zeros over xGMI
+// is half of the collective's bytes: the caller that knows its stream is mirrored reduces from that row on.
+int gridhip_comm_allreduce_rows(gridhip_comm *c, int64_t Wd, int64_t y0, int64_t y1, double *const *grids)
+{
+    if (!c || !grids) return GRIDHIP_EINVAL;
+    if (Wd <= 0 || y0 < 0 || y1 < y0) return comm_fail(c, GRIDHIP_EINVAL, "bad row range");
+    std::vector<double *> p(c->ctx.size());
+    for (size_t i = 0; i < c->ctx.size(); ++i) {
+        if (!grids[i] && y1 > y0) return comm_fail(c, GRIDHIP_EINVAL, "null grid pointer");
+        p[i] = grids[i] + 2 * (size_t)y0 * (size_t)Wd;
+    }
+    return comm_sum_doubles(c, (size_t)(y1 - y0) * (size_t)Wd * 2, p.data());
+}
+
+int gridhip_comm_allreduce_grid_rows(gridhip_comm *c, int64_t Wd, int64_t y0, int64_t y1, double *grid)
+{
+    if (!c || c->ctx.size() != 1) return comm_fail(c, GRIDHIP_EINVAL, "rank form only: this communicator drives several devices");
+    double *g[1] = {grid};
+    return gridhip_comm_allreduce_rows(c, Wd, y0, y1, g);
+}
+
+int gridhip_comm_set_option(gridhip_comm *c, const char *key, int64_t value)
+{
+    if (!c || !key) return GRIDHIP_EINVAL;
+    if (!strcmp(key, "collective")) {
+        if (value != 0 && value != 1) return comm_fail(c, GRIDHIP_EINVAL, "collective: 0 = all-reduce, 1 = reduce-scatter + all-gather");
+        c->collective = (int)value;
+        return GRIDHIP_OK;
+    }
+    return comm_fail(c, GRIDHIP_EINVAL, std::string("unknown communicator option '") + key + "'");
+}
+
+int gridhip_comm_get_option(gridhip_comm *c, const char *key, int64_t *value)
+{
+    if (!c || !key || !value) return GRIDHIP_EINVAL;
+    if (!strcmp(key, "collective")) {
+        *value = c->collective;
+        return GRIDHIP_OK;
+    }
+    return comm_fail(c, GRIDHIP_EINVAL, std::string("unknown communicator option '") + key + "'");
+}
+
+int gridhip_comm_set_stream(gridhip_comm *c, int i, void *hip_stream)
+{
+    if (!c || i < 0 || i >= (int)c->ctx.size()) return GRIDHIP_EINVAL;
+    c->cstream[i] = (hipStream_t)hip_stream;
+    c->has_cstream[i] = 1;
+    return GRIDHIP_OK;
+}
+
+int gridhip_comm_reset_stream(gridhip_comm *c, int i)
+{
+    if (!c || i < 0 || i >= (int)c->ctx.size()) return GRIDHIP_EINVAL;
+    c->has_cstream[i] = 0;
+    return GRIDHIP_OK;
 }
 
 // convgrid2 (src/Gridding.hs:199-244) over the communicator's devices, host pointers, synchronous: the drop-in
@@ -294,16 +423,43 @@ int gridhip_comm_convgrid2(gridhip_comm *c, int64_t H, int64_t Wd, double *grid,
         for (int i = 0; i < nd; ++i) th.emplace_back(work, i);
         for (auto &t : th) t.join();
     }
+    // A shard that failed locally must not leave the other devices (or, in the rank form, the other PROCESSES) waiting
+    // in the collective for ever: every device still takes part in the all-reduce - with whatever its grid buffer
+    // holds - and the failure is reported afterwards; the caller's grid is then left untouched.
+    int first_bad = -1;
     for (int i = 0; i < nd; ++i)
-        if (rcs[i] != GRIDHIP_OK) return comm_fail(c, rcs[i], std::string("device shard failed: ") + c->ctx[i]->err);
-    if (c->nranks > 1) GH_CHECK(gridhip_comm_allreduce_grids(c, (int64_t)cells, dgrid.data()));
+        if (rcs[i] != GRIDHIP_OK && first_bad < 0) first_bad = i;
+    bool staged = true;
+    for (int i = 0; i < nd; ++i) staged = staged && dgrid[i] != nullptr;
+    // (the synchronous form reduces on the gridding streams, whatever gridhip_comm_set_stream chose for the async one)
+    const std::vector<char> keep = c->has_cstream;
+    c->has_cstream.assign(nd, 0);
+    int rc_coll = GRIDHIP_OK;
+    if (c->nranks > 1 && staged) rc_coll = gridhip_comm_allreduce_grids(c, (int64_t)cells, dgrid.data());
+    c->has_cstream = keep;
+    if (first_bad >= 0) {
+        for (int i = 0; i < nd; ++i) {
+            (void)hipSetDevice(c->ctx[i]->device);
+            (void)hipStreamSynchronize(c->ctx[i]->stream);
+        }
+        return comm_fail(c, rcs[first_bad], std::string("device shard failed: ") + c->ctx[first_bad]->err);
+    }
+    GH_CHECK(rc_coll);
+    // internal consistency failures of any shard (records that did not fit, slices outside the table: "errors") are
+    // reported instead of a silently incomplete grid, as gridhip_convgrid2 does
+    for (int i = 0; i < nd; ++i) {
+        gridhip_ctx *x = c->ctx[i];
+        GH_CHECK_HIP(x, hipSetDevice(x->device));
+        int32_t e = 0;
+        GH_CHECK_HIP(x, hipMemcpyAsync(&e, x->d_scalars + 2, sizeof e, hipMemcpyDeviceToHost, x->stream));
+        GH_CHECK_HIP(x, hipStreamSynchronize(x->stream));
+        if (e) return comm_fail(c, GRIDHIP_EINVAL, "internal consistency check failed on device " + std::to_string(x->device) +
+                                                       " for " + std::to_string(e) + " records (inputs modified during the call?)");
+    }
     gridhip_ctx *x0 = c->ctx[0];
     GH_CHECK_HIP(x0, hipSetDevice(x0->device));
     GH_CHECK_HIP(x0, hipMemcpyAsync(grid, dgrid[0], cells * 16, hipMemcpyDeviceToHost, x0->stream));
-    for (int i = 0; i < nd; ++i) {
-        GH_CHECK_HIP(c->ctx[i], hipSetDevice(c->ctx[i]->device));
-        GH_CHECK_HIP(c->ctx[i], hipStreamSynchronize(c->ctx[i]->stream));
-    }
+    GH_CHECK_HIP(x0, hipStreamSynchronize(x0->stream));
     return GRIDHIP_OK;
 }
 

@@ -107,7 +107,7 @@ __host__ __device__ __forceinline__ RecWord rec_pack(const Geom &g, int32_t lxy,
 }
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0, rec_bits = 0, wtable = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0, rec_bits = 0, wtable = 0, reserve_cus = 0;
 };
 
 struct Workspace {
@@ -121,6 +121,7 @@ struct gridhip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t order_ev = nullptr;  // orders a newly selected stream after the previous one (gridhip_set_stream)
     std::string err;
     gridhip::Options opt;
     // device scratch, grown on demand (never inside a timed/captured region after warm-up)

@@ -262,6 +262,10 @@ int gridhip_create(int device, gridhip_ctx **out)
         return GRIDHIP_EHIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming) != hipSuccess) {
+        gridhip_destroy(ctx);
+        return GRIDHIP_EHIP;
+    }
     if (hipMalloc((void **)&ctx->d_scalars, 128 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(ctx->d_scalars, 0, 128 * sizeof(int32_t)) != hipSuccess) {
         gridhip_destroy(ctx);
@@ -288,6 +292,7 @@ int gridhip_destroy(gridhip_ctx *ctx)
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     for (int i = 0; i < gridhip_ctx::EV_RING * 3; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GRIDHIP_OK;
@@ -295,20 +300,37 @@ int gridhip_destroy(gridhip_ctx *ctx)
 
 const char *gridhip_last_error(const gridhip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// Every call on a context shares its scratch (records, tables, sorted lists, padded kernels, aw tables): work
+// enqueued on the stream selected next must not start before what the previous stream still has queued is done with
+// them.  An event recorded on the old stream, waited for by the new one - unless either is being captured into a
+// graph (a capture may not depend on work outside it; the caller keeps one stream per context there).
+static int switch_stream(gridhip_ctx *ctx, hipStream_t next)
+{
+    if (next == ctx->stream) return GRIDHIP_OK;
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &a);
+    (void)hipStreamIsCapturing(next, &b);
+    if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) {
+        GH_CHECK_HIP(ctx, hipEventRecord(ctx->order_ev, ctx->stream));
+        GH_CHECK_HIP(ctx, hipStreamWaitEvent(next, ctx->order_ev, 0));
+    }
+    ctx->stream = next;
+    return GRIDHIP_OK;
+}
+
 int gridhip_set_stream(gridhip_ctx *ctx, void *s)
 {
     if (!ctx) return GRIDHIP_EINVAL;
     // NULL is a real stream: HIP's default ("null") stream, which is what torch.cuda.current_stream()
     // is until the caller switches streams.  Work is enqueued exactly where the caller's own work is.
-    ctx->stream = (hipStream_t)s;
-    return GRIDHIP_OK;
+    return switch_stream(ctx, (hipStream_t)s);
 }
 
 int gridhip_reset_stream(gridhip_ctx *ctx)
 {
     if (!ctx) return GRIDHIP_EINVAL;
-    ctx->stream = ctx->own_stream;
-    return GRIDHIP_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 void *gridhip_get_stream(gridhip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -342,6 +364,7 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "count_unroll")) return &ctx->opt.count_unroll;
     if (!strcmp(key, "rec_bits")) return &ctx->opt.rec_bits;
     if (!strcmp(key, "wtable")) return &ctx->opt.wtable;
+    if (!strcmp(key, "reserve_cus")) return &ctx->opt.reserve_cus;
     return nullptr;
 }
 

@@ -644,8 +644,11 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     int per_cu = (int)((size_t)ctx->max_lds / lds_bytes);
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
     if (per_cu * block > 2048) per_cu = 2048 / block > 0 ? 2048 / block : 1;
-    int nblk = ctx->num_cu * per_cu;
-    nblk = ((nblk + g.ngroups - 1) / g.ngroups) * g.ngroups;
+    // option "reserve_cus": leave k compute units without a work-group, for a collective queued on another stream
+    int cus = ctx->num_cu - (int)ctx->opt.reserve_cus;
+    if (cus < g.ngroups) cus = g.ngroups;
+    int nblk = cus * per_cu;
+    nblk = ctx->opt.reserve_cus ? (nblk / g.ngroups) * g.ngroups : ((nblk + g.ngroups - 1) / g.ngroups) * g.ngroups;
     const int most = work_blocks(g, n);
     if (nblk > most) nblk = most > g.ngroups ? (most / g.ngroups) * g.ngroups : g.ngroups;
     const dim3 gr(nblk), bl(block);

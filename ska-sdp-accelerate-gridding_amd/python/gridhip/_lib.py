@@ -76,6 +76,12 @@ SIGNATURES = {
     "gridhip_comm_ctx": (vp, [vp, ci]),
     "gridhip_comm_allreduce_grids": (ci, [vp, i64, C.POINTER(vp)]),
     "gridhip_comm_allreduce_grid": (ci, [vp, i64, vp]),
+    "gridhip_comm_allreduce_rows": (ci, [vp, i64, i64, i64, C.POINTER(vp)]),
+    "gridhip_comm_allreduce_grid_rows": (ci, [vp, i64, i64, i64, vp]),
+    "gridhip_comm_set_option": (ci, [vp, C.c_char_p, i64]),
+    "gridhip_comm_get_option": (ci, [vp, C.c_char_p, C.POINTER(i64)]),
+    "gridhip_comm_set_stream": (ci, [vp, ci, vp]),
+    "gridhip_comm_reset_stream": (ci, [vp, ci]),
     "gridhip_comm_convgrid2": (ci, [vp] + _CONV2_DEV[1:]),
     "gridhip_malloc": (ci, [vp, C.POINTER(vp), i64]),
     "gridhip_free": (ci, [vp, vp]),

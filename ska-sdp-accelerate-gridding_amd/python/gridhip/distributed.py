@@ -18,18 +18,27 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_grid(grid, group=None, async_op=False):
+def mirrored_first_row(H, gh):
+    """First grid row a mirrored stream (mirror_uvw, src/Gridding.hs:551-562: v >= 0) can touch: frac_coord puts
+    v >= 0 at y >= H div 2 (floor (H/2 + v H + 0.5/Q) with v H >= 0) and the footprint starts gh div 2 rows below its
+    centre (:170-171); one more row of margin.  Rows below it are exactly zero in every partial grid, so the
+    all-reduce may skip them (half of its bytes)."""
+    return max(0, H // 2 - gh // 2 - 1)
+
+
+def allreduce_grid(grid, group=None, async_op=False, rows=None):
     """In-place fp64 sum of a complex128 grid over all ranks.
 
-    torch tensor (cpu or cuda) or numpy array (wrapped without a copy).  Returns the grid, or with
-    async_op=True the torch.distributed work handle (its .wait() orders the current stream after
-    the collective)."""
+    torch tensor (cpu or cuda) or numpy array (wrapped without a copy).  rows = (y0, y1): only those rows (a
+    contiguous slice of the row-major grid).  Returns the grid, or with async_op=True the torch.distributed work
+    handle (its .wait() orders the current stream after the collective)."""
     import torch
     import torch.distributed as dist
-    if isinstance(grid, np.ndarray):
-        t = torch.from_numpy(grid.view(np.float64))
+    part = grid if rows is None else grid[rows[0]:rows[1]]
+    if isinstance(part, np.ndarray):
+        t = torch.from_numpy(part.view(np.float64))
     else:
-        t = torch.view_as_real(grid)
+        t = torch.view_as_real(part)
     work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return work if async_op else grid
 
@@ -40,11 +49,12 @@ class OverlappedGridReducer:
     tensors used alternately; call begin(i) before gridding onto grids[i % 2], end(i) after the
     gridding has been enqueued on the current stream, finish() before reading results."""
 
-    def __init__(self, grids, group=None):
+    def __init__(self, grids, group=None, rows=None):
         import torch
         self.torch = torch
         self.grids = grids
         self.group = group
+        self.rows = rows  # (y0, y1): reduce these rows only (mirrored streams: mirrored_first_row)
         self.comm = torch.cuda.Stream(device=grids[0].device)
         self.work = [None, None]
 
@@ -65,7 +75,7 @@ class OverlappedGridReducer:
         ev.record()
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ev)
-            self.work[i % 2] = allreduce_grid(self.grids[i % 2], self.group, async_op=True)
+            self.work[i % 2] = allreduce_grid(self.grids[i % 2], self.group, async_op=True, rows=self.rows)
 
     def finish(self):
         for k in (0, 1):
@@ -73,6 +83,56 @@ class OverlappedGridReducer:
                 self.work[k].wait()
                 self.work[k] = None
         self.torch.cuda.current_stream().wait_stream(self.comm)
+
+
+class OverlappedCommReducer:
+    """OverlappedGridReducer over libgridhip's own communicator (Comm, rank form) instead of torch.distributed: the
+    collective (option "collective": all-reduce, or reduce-scatter + all-gather) is enqueued by RCCL on a side stream
+    handed to the communicator (gridhip_comm_set_stream), ordered after the step's gridding by an event and waited
+    for, by event, before the buffer is written again.  Same protocol: begin(i) / end(i) / finish()."""
+
+    def __init__(self, comm, grids, rows=None):
+        import torch
+        self.torch = torch
+        self.c = comm
+        self.grids = grids
+        self.rows = rows
+        self.side = torch.cuda.Stream(device=grids[0].device)
+        comm.set_stream(self.side.cuda_stream)
+        self.done = [None, None]
+
+    def begin(self, i, zero=True):
+        ev = self.done[i % 2]
+        if ev is not None:
+            self.torch.cuda.current_stream().wait_event(ev)  # this buffer's previous reduction
+            self.done[i % 2] = None
+        if zero:
+            self.grids[i % 2].zero_()
+        return self.grids[i % 2]
+
+    def end(self, i):
+        torch = self.torch
+        ev = torch.cuda.Event()
+        ev.record()  # after the step's gridding on the current stream
+        self.side.wait_event(ev)
+        g = self.grids[i % 2]
+        if self.rows is None:
+            self.c.allreduce_grid(g)
+        else:
+            self.c.allreduce_grid_rows(g, *self.rows)
+        d = torch.cuda.Event()
+        d.record(self.side)
+        self.done[i % 2] = d
+
+    def finish(self):
+        for k in (0, 1):
+            if self.done[k] is not None:
+                self.torch.cuda.current_stream().wait_event(self.done[k])
+                self.done[k] = None
+
+    def close(self):
+        self.finish()
+        self.c.reset_stream()
 
 
 def sharded_convgrid2(gridder, gcf, a, p, wbin, v, rank, world, group=None, reduce=True):
@@ -155,6 +215,40 @@ class Comm:
         if rc != 0:
             raise self._err(self._lib, rc, self._h)
         return grid
+
+    def allreduce_grid_rows(self, grid, y0, y1):
+        """The same for rows [y0, y1) only (gridhip_comm_allreduce_grid_rows)."""
+        import ctypes as C
+        assert grid.dim() == 2 and grid.is_contiguous() and 0 <= y0 <= y1 <= grid.shape[0]
+        rc = self._lib.gridhip_comm_allreduce_grid_rows(self._h, grid.shape[1], int(y0), int(y1), C.c_void_p(grid.data_ptr()))
+        if rc != 0:
+            raise self._err(self._lib, rc, self._h)
+        return grid
+
+    def set_option(self, key, value):
+        rc = self._lib.gridhip_comm_set_option(self._h, key.encode(), int(value))
+        if rc != 0:
+            raise self._err(self._lib, rc, self._h)
+
+    def get_option(self, key):
+        import ctypes as C
+        v = C.c_int64()
+        rc = self._lib.gridhip_comm_get_option(self._h, key.encode(), C.byref(v))
+        if rc != 0:
+            raise self._err(self._lib, rc, self._h)
+        return v.value
+
+    def set_stream(self, stream_ptr, i=0):
+        """Enqueue device i's collectives on this hipStream_t instead of its context's stream."""
+        import ctypes as C
+        rc = self._lib.gridhip_comm_set_stream(self._h, int(i), C.c_void_p(stream_ptr or 0))
+        if rc != 0:
+            raise self._err(self._lib, rc, self._h)
+
+    def reset_stream(self, i=0):
+        rc = self._lib.gridhip_comm_reset_stream(self._h, int(i))
+        if rc != 0:
+            raise self._err(self._lib, rc, self._h)
 
     def convgrid2(self, gcf, a, p, wbin, v):
         """convgrid2 over all devices of the communicator, numpy host arrays (gridhip_comm_convgrid2)."""

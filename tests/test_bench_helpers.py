@@ -64,6 +64,61 @@ def test_traffic_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path, mon
     assert bench.committed_traffic("cfg2")[0] is None
 
 
+def test_counter_based_stream_is_the_same_everywhere():
+    """a counter-based generator, identical on CPU and GPU, so that any rank can draw any range of the
+    one global stream.  The numpy uint64 twin reproduces torch's int64 arithmetic bit for bit, a range drawn on its
+    own equals that range of the whole stream, and the stream has the properties the bench relies on (every tap in
+    range, mirrored to v >= 0, w-bins inside the table)."""
+    import numpy as np
+    import torch
+    seed = 0x5EEDC0DE
+    k = np.arange(12345, 12345 + 4096)
+    for j in range(8):
+        a = bench.counter_uniform_numpy(seed, k, j)
+        b = bench.counter_uniform(seed, torch.from_numpy(k), j).numpy()
+        assert np.array_equal(a, b) and a.min() >= 0.0 and a.max() < 1.0
+    N, W, S = 4096, 128, 15
+    dev = torch.device("cpu")
+    whole = bench.synth_vis(5000, N, W, S, seed, dev)
+    for lo, hi in ((0, 1250), (1250, 3750), (3750, 5000)):
+        part = bench.synth_vis(hi - lo, N, W, S, seed, dev, lo=lo)
+        for x, y in zip(whole, part):
+            assert torch.equal(x[lo:hi], y)
+    u, v, wb, vis = whole
+    m = (S / 2 + 1) / N
+    assert u.abs().max() <= 0.5 - m and v.min() >= 0.0 and v.max() <= 0.5 - m
+    assert wb.min() >= 0 and wb.max() <= W - 1 and len(torch.unique(wb)) > 100
+    # u from the twin: (U - 0.5) * (1 - 2 m), mirrored where v < 0 - single IEEE operations, so bit-exact on any device
+    pu = (bench.counter_uniform_numpy(seed, np.arange(5000), 0) - 0.5) * (1 - 2 * m)
+    pv = (bench.counter_uniform_numpy(seed, np.arange(5000), 1) - 0.5) * (1 - 2 * m)
+    assert np.array_equal(np.where(pv < 0, -pu, pu), u.numpy()) and np.array_equal(np.abs(pv), v.numpy())
+    other = bench.synth_vis(100, N, W, S, seed + 1, dev)
+    assert not torch.equal(other[0], u[:100])
+    core = bench.synth_vis(2000, N, W, S, seed, dev, dist="core")
+    assert core[0].std() < 0.12 and core[1].min() >= 0.0
+
+
+def test_expected_checksum_is_what_the_oracle_grids(oracle):
+    """The bench line's self-check: sum(G) of a correct convgrid2 equals sum_k vis_k * sum_ij K[slice_k] when every tap
+    is in range.  Here the C oracle is the gridder; the mirrored stream leaves the rows below mirrored_first_row zero."""
+    import numpy as np
+    import torch
+    from gridhip.distributed import mirrored_first_row
+    N, W, Q, S, n = 256, 8, 4, 7, 20000
+    dev = torch.device("cpu")
+    u, v, wb, vis = bench.synth_vis(n, N, W, S, 99, dev)
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    G = np.zeros((N, N), dtype=np.complex128)
+    oracle.convgrid2(gcf.numpy(), G, u.numpy(), v.numpy(), wb.numpy(), vis.numpy())
+    expect, scale = bench.expected_checksum(u, v, wb, vis, gcf, N)
+    assert abs(G.sum() - complex(expect.item())) / scale.item() < 1e-13
+    y0 = mirrored_first_row(N, S)
+    assert y0 == N // 2 - S // 2 - 1 and not G[:y0].any() and G[y0 + 1].any()
+    # a visibility short, or a wrong slice, is seen
+    e2, _ = bench.expected_checksum(u[:-1], v[:-1], wb[:-1], vis[:-1], gcf, N)
+    assert abs(G.sum() - complex(e2.item())) / scale.item() > 1e-8
+
+
 def test_plain_command_spawns_the_ranks():
     """`python bench.py --gpus 2` as a plain command starts the two rank processes itself (before any GPU call) and
     relays rank 0's line; --dry-run keeps the rendezvous on gloo so this runs on a CPU box."""

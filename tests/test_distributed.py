@@ -72,3 +72,63 @@ def test_two_rank_gloo_sharded_grid_matches_single_process():
     assert sorted(r for r, _ in res) == [0, 1]
     for _, err in res:
         assert err < 1e-12  # same tolerance class as the GPU parity (summation order differs)
+
+
+def _bench_worker(rank, world, port, scaling, q):
+    """bench.py's N > 1 bookkeeping on two gloo ranks, the C oracle standing in for the GPU gridder: one global
+    counter-based stream, rank r grids its range, only the rows a mirrored stream can touch are all-reduced, and
+    every rank certifies the reduced grid against the all-reduced analytic checksum."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "python"))
+    import torch
+    import torch.distributed as dist
+    import bench
+    from gridhip.distributed import allreduce_grid, mirrored_first_row, shard_bounds
+    from oracle import gridref_c
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, W, Q, S, n = 192, 8, 4, 7, 6001
+    dev = torch.device("cpu")
+    if scaling == "strong":
+        n_total = n
+        lo, hi = shard_bounds(n_total, world, rank)
+    else:
+        n_total = n * world
+        lo, hi = rank * n, (rank + 1) * n
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    u, v, wb, vis = bench.synth_vis(hi - lo, N, W, S, 0x5EEDC0DE, dev, lo=lo)
+    G = np.zeros((N, N), dtype=np.complex128)
+    gridref_c.convgrid2(gcf.numpy(), G, u.numpy(), v.numpy(), wb.numpy(), vis.numpy())
+    rows = (mirrored_first_row(N, S), N)
+    allreduce_grid(G, rows=rows)
+    expect, scale = bench.expected_checksum(u, v, wb, vis, gcf, N)
+    ex = torch.stack([expect.real, expect.imag, scale])
+    dist.all_reduce(ex)
+    rel = abs(G.sum() - complex(ex[0].item(), ex[1].item())) / ex[2].item()
+    # and against the one-process grid of the whole stream
+    U, V, WB, VIS = bench.synth_vis(n_total, N, W, S, 0x5EEDC0DE, dev)
+    ref = gridref_c.convgrid2(gcf.numpy(), np.zeros((N, N), dtype=np.complex128), U.numpy(), V.numpy(), WB.numpy(), VIS.numpy())
+    q.put((rank, float(rel), float(np.abs(G - ref).max() / np.abs(ref).max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_rank_gloo_bench_sharding_rows_and_checksum(scaling):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, scaling, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, "worker failed"
+    res = [q.get(timeout=10) for _ in range(2)]
+    for _, rel, err in res:
+        assert rel < 1e-12 and err < 1e-12

@@ -106,7 +106,70 @@ def test_cabi_communicator_rank_form_and_single_process_form():
     assert rec["sizes"] == [1, 1] and rec["same"] and rec["bad"] == -1
 
 
-@pytest.mark.parametrize("collective", ["torch", "cabi"])
+def test_cabi_rows_reduce_scatter_and_side_stream_with_one_rank():
+    """The pieces the 8-GPU run depends on, each with a communicator of one rank: the reduce-scatter + all-gather form
+    of the collective, the rows-only form, both on a side stream handed to the communicator, driven by
+    OverlappedCommReducer over five steps and two buffers while the tile kernel leaves CUs free (reserve_cus)."""
+    rec = run_child("""
+        import json
+        from gridhip.distributed import OverlappedCommReducer, mirrored_first_row
+        comm = Comm.from_torch(ctx)
+        out = {"default": comm.get_option("collective")}
+        try:
+            comm.set_option("collective", 7)
+            out["bad"] = 0
+        except gridhip.GridHipError as e:
+            out["bad"] = e.code
+        try:
+            comm.set_option("no_such_option", 1)
+            out["bad2"] = 0
+        except gridhip.GridHipError as e:
+            out["bad2"] = e.code
+        ctx.set_option("reserve_cus", 16)
+        tg, tw, tv = T(gcf), T(wb), T(vis)
+        errs = {}
+        for name, coll, rows in (("ar_rows", 0, (40, N)), ("rs", 1, None), ("rs_rows", 1, (3, N - 5))):
+            comm.set_option("collective", coll)
+            bufs = [torch.zeros((N, N), dtype=torch.complex128, device=dev) for _ in range(2)]
+            red = OverlappedCommReducer(comm, bufs, rows=rows)
+            e = []
+            for i in range(5):
+                g = red.begin(i)
+                ctx.convgrid2(tg, g, (T(us[i]), T(vs[i]), None), tw, tv)
+                red.end(i)
+                if i >= 1:
+                    red.done[(i - 1) % 2].synchronize()
+                    e.append(relerr(bufs[(i - 1) % 2].cpu().numpy(), refs[i - 1]))
+            red.finish()
+            torch.cuda.synchronize()
+            e.append(relerr(bufs[0].cpu().numpy(), refs[4]))
+            red.close()
+            errs[name] = max(e)
+        out["errs"] = errs
+        out["collective"] = comm.get_option("collective")
+        out["errors"] = ctx.get_option("errors")
+        out["reserve"] = ctx.get_option("reserve_cus")
+        # direct calls on the context's own stream again (reset by close())
+        g = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+        ctx.convgrid2(tg, g, (T(us[0]), T(vs[0]), None), tw, tv)
+        comm.allreduce_grid_rows(g, 0, N)
+        comm.allreduce_grid_rows(g, 17, 17)   # empty range
+        ctx.synchronize()
+        out["direct"] = relerr(g.cpu().numpy(), refs[0])
+        try:
+            comm.allreduce_grid_rows(g, 5, N + 1)
+            out["bad3"] = 0
+        except AssertionError:
+            out["bad3"] = 1
+        comm.close()
+        print(json.dumps(out))
+        dist.destroy_process_group()
+    """)
+    assert rec["default"] == 0 and rec["bad"] == -1 and rec["bad2"] == -1 and rec["collective"] == 1 and rec["bad3"] == 1
+    assert max(rec["errs"].values()) < 1e-10 and rec["direct"] < 1e-10 and rec["errors"] == 0 and rec["reserve"] == 16
+
+
+@pytest.mark.parametrize("collective", ["torch", "cabi", "cabi-rs"])
 def test_bench_multi_gpu_branch_with_one_rank(collective):
     """bench.py's N > 1 branch (process group, reducer / communicator, all-reduce timing, multi_gpu record)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -118,6 +181,9 @@ def test_bench_multi_gpu_branch_with_one_rank(collective):
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["multi_gpu"]["rccl_ranks"] == 1 and rec["multi_gpu"]["collective"] == collective
     assert rec["multi_gpu"]["allreduce_ms_alone"] > 0 and rec["errors"] == 0
+    assert rec["check"]["rel_err"] <= 1e-10 and rec["multi_gpu"]["check_rel_err"] == rec["check"]["rel_err"]
+    assert rec["multi_gpu"]["reduced_rows"] == [4096 // 2 - 15 // 2 - 1, 4096] and rec["multi_gpu"]["reserve_cus"] == 16
+    assert rec["scaling"] == "weak" and rec["multi_gpu"]["scaling"] == "weak"
     assert 0 < rec["roofline"]["frac"] <= 1 and 0 < rec["roofline"]["lds_floor_frac"] <= 1
     assert rec["roofline"]["bound"] == "lds_atomic" and 1.0 < rec["roofline"]["clock_GHz"] < 2.6
 
@@ -131,6 +197,38 @@ def test_bench_default_line_is_bounded():
     assert 0 < r["frac"] <= 1 and 0 < r["lds_floor_frac"] <= 1 and r["kernel_ms"]["min"] <= r["kernel_ms"]["median"]
     assert rec["cpu_baseline"]["cores"] >= 1 and len(rec["cpu_baseline"]["modes"]) == 3
     assert rec["cpu_baseline"]["cpu_model"] and rec["value"] > 0
+    # the line certifies itself: checksum of every grid the steps produced, and the GPU's grid of the CPU baseline's
+    # sample against the oracle's, cell by cell
+    c = rec["check"]
+    assert c["rel_err"] <= 1e-10 and c["cells_nonzero"] > 1000 and c["grids_checked"] == 4 and c["seconds"] < 5.0
+    assert rec["cpu_baseline"]["parity_rel_err"] <= 1e-10 and rec["errors"] == 0
+
+
+def _bench(*extra, env=None):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", *extra],
+                         capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out.returncode, (json.loads(lines[-1]) if lines else None), out.stderr
+
+
+def test_bench_strong_scaling_on_one_gpu_is_the_weak_line():
+    """With one GPU both modes draw the same range of the same global stream: same grids (cells_nonzero), same check."""
+    rc_w, weak, err_w = _bench("--nvis", "3000000")
+    rc_s, strong, err_s = _bench("--nvis", "3000000", "--scaling", "strong")
+    assert rc_w == 0 and rc_s == 0, (err_w[-2000:], err_s[-2000:])
+    assert weak["scaling"] == "weak" and strong["scaling"] == "strong"
+    for k in ("vis_total", "vis_per_gpu", "seed"):
+        assert weak["config"][k] == strong["config"][k]
+    assert weak["check"]["cells_nonzero"] == strong["check"]["cells_nonzero"]
+    assert weak["check"]["rel_err"] <= 1e-10 and strong["check"]["rel_err"] <= 1e-10
+
+
+def test_bench_fails_loudly_when_the_result_is_wrong():
+    """fault_inject hides record slots from the pre-pass: visibilities are lost, the library counts errors, the
+    checksum is off - the process must exit non-zero, not print a number as if nothing had happened."""
+    rc, rec, err = _bench("--nvis", "3000000", "--opt", "fault_inject=5000")
+    assert rc != 0 and "RESULT CHECK FAILED" in err
+    assert rec is not None and rec["errors"] > 0 and rec["check"]["rel_err"] > 1e-10
 
 
 def test_two_ranks_share_one_gpu_over_gloo():

@@ -735,3 +735,43 @@ def test_checksum_property_large(ctx, N, n):
     ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
     torch.cuda.synchronize()
     assert (G.abs().max().item() / gmax) < 1e-11  # back to zero up to rounding
+
+
+def test_alternating_streams_share_the_context_scratch_safely(ctx, oracle):
+    """A context has one set of scratch buffers.  Calls issued alternately on two streams, with no host
+    synchronisation in between, must not overwrite records another stream's kernels are still reading:
+    gridhip_set_stream orders the new stream after the old one."""
+    import torch
+    dev = torch.device("cuda:0")
+    N, W, Q, S, n = 512, 8, 4, 9, 400000
+    cases = [case(300 + i, N, N, W, Q, S, S, n, spread=0.5) for i in range(2)]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    dc = [tuple(t(a) for a in c) for c in cases]
+    refs = [oracle.convgrid2(c[0], np.zeros((N, N), dtype=np.complex128), c[1], c[2], c[3], c[4]) for c in cases]
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    G = [torch.zeros((N, N), dtype=torch.complex128, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for k in (0, 1):
+            with torch.cuda.stream(s[k]):
+                gcf, u, v, wb, vis = dc[k]
+                ctx.convgrid2(gcf, G[k], (u, v, None), wb, vis)
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        err = np.abs(G[k].cpu().numpy() / 6 - refs[k]).max() / np.abs(refs[k]).max()
+        assert err < 1e-10
+    assert ctx.get_option("errors") == 0
+
+
+def test_reserved_cus_do_not_change_the_grid(ctx, oracle):
+    gcf, u, v, wb, vis = case(77, 384, 384, 8, 4, 15, 15, 300000, spread=0.5)
+    ref = oracle.convgrid2(gcf, np.zeros((384, 384), dtype=np.complex128), u, v, wb, vis)
+    try:
+        for k in (8, 32, 250, 1000):
+            ctx.set_option("reserve_cus", k)
+            ctx.set_option("sort", 1)
+            got = ctx.convgrid2(gcf, np.zeros((384, 384), dtype=np.complex128), (u, v, None), wb, vis)
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-10
+    finally:
+        ctx.set_option("reserve_cus", 0)
+        ctx.set_option("sort", 0)

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""What does the "reserve_cus" option cost the tile kernel on one GPU, and does a kernel queued on another stream
+really start beside the persistent tile kernel once CUs are left free?
+
+The stand-in for the collective is a device-to-device copy of the rows a mirrored 4096^2 grid reduces (137 MB read +
+137 MB written; an RCCL all-reduce kernel is, like it, a few work-groups that stream memory), enqueued on a side stream
+right after the tile kernel has been launched.  Reported per k: the cfg3 step alone, the step with the copy beside it,
+and when the copy finished relative to the step's start - "copy_end < step_end" means it ran beside the tile kernel
+instead of after it.  usage: python tools/reserve_cus_probe.py [cfg3|cfg5]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "python"))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import gridhip  # noqa: E402
+from gridhip.distributed import mirrored_first_row  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+n, N, W, Q, S = bench.WORKLOADS[wl]
+dev = torch.device("cuda:0")
+ctx = gridhip.Context(0)
+gcf = bench.synth_kernels(W, Q, S, dev)
+u, v, wb, vis = bench.synth_vis(n, N, W, S, 0x5EEDC0DE, dev)
+G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+y0 = mirrored_first_row(N, S)
+src = torch.zeros((N - y0, N), dtype=torch.complex128, device=dev)
+dst = torch.empty_like(src)
+side = torch.cuda.Stream()
+ev = lambda: torch.cuda.Event(enable_timing=True)
+
+
+def step():
+    ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+
+
+print(f"# {wl}: {n} vis, {N}^2 grid, {S}x{S}; stand-in collective: copy of rows [{y0}, {N}) = {src.numel() * 16 / 1e6:.0f} MB")
+with torch.cuda.stream(side):
+    a, b = ev(), ev()
+    dst.copy_(src)
+    a.record()
+    dst.copy_(src)
+    b.record()
+torch.cuda.synchronize()
+print(f"copy alone: {a.elapsed_time(b):.3f} ms")
+print("reserve_cus  step_alone_ms  kernel_alone_ms  step_with_copy_ms  copy_end_after_step_start_ms  copy_ran_beside")
+for k in (0, 4, 8, 16, 32, 64):
+    ctx.set_option("reserve_cus", k)
+    ctx.enable_timing(True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    alone, kern = [], []
+    for _ in range(5):
+        t0, t1 = ev(), ev()
+        t0.record()
+        step()
+        t1.record()
+        torch.cuda.synchronize()
+        alone.append(t0.elapsed_time(t1))
+        kern.append(ctx.last_timing()[2])
+    both, cend = [], []
+    for _ in range(5):
+        t0, t1, c1 = ev(), ev(), ev()
+        t0.record()
+        step()
+        t1.record()
+        with torch.cuda.stream(side):
+            dst.copy_(src)
+            c1.record()
+        torch.cuda.synchronize()
+        both.append(t0.elapsed_time(t1))
+        cend.append(t0.elapsed_time(c1))
+    med = lambda x: sorted(x)[len(x) // 2]
+    print(f"{k:11d}  {med(alone):13.3f}  {med(kern):15.3f}  {med(both):17.3f}  {med(cend):28.3f}  {'yes' if med(cend) < med(both) - 0.5 else 'no'}",
+          flush=True)
+ctx.set_option("reserve_cus", 0)
