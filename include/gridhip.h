@@ -237,6 +237,18 @@ int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int
                        int64_t gh, int64_t gw, const double *kv, double theta, int64_t lam, int64_t n,
                        const double *u, const double *v, const double *w, int64_t uv_stride,
                        const double *vis, double *image, double *psf, double *pmax);
+/* The same with every array argument resident on the device (kv, u, v, w, vis in; image, psf out: ordinary device
+ * allocations): nothing crosses PCIe, and after the first call of a shape nothing is allocated or freed (the scratch
+ * comes from a pool the context keeps).  pmax stays a HOST pointer (may be NULL).  The call synchronises the stream
+ * (the w-bin rule reads min / max back to the host exactly as the reference's nested CPU.run does, :430). */
+int gridhip_do_imaging_dev(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int64_t npixFF, int64_t gh,
+                           int64_t gw, const double *kv, double theta, int64_t lam, int64_t n, const double *u,
+                           const double *v, const double *w, int64_t uv_stride, const double *vis, double *image,
+                           double *psf, double *pmax);
+/* w_cache_imaging with device-resident u, v, w (wavelengths), vis and N x N grid (overwritten). */
+int gridhip_w_cache_imaging_dev(gridhip_ctx *ctx, int64_t wstep, int64_t qpx, int64_t npixFF, int64_t npixKern,
+                                double theta, int64_t lam, int64_t n, const double *u, const double *v,
+                                const double *w, int64_t uv_stride, const double *vis, double *grid);
 
 /* ---- multi-GPU: visibility-sharded gridding + one RCCL fp64 sum all-reduce of the partial grids ------
  * Gridding is linear in the visibility set, so the path shards by visibility with no data-path exchange; the

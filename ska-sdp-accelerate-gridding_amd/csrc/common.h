@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string>
 #include <unordered_set>
+#include <utility>
+#include <vector>
 
 #include "../../include/gridhip.h"
 
@@ -152,6 +154,11 @@ struct gridhip_ctx {
     void *fft_plan[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t fft_n[4] = {0, 0, 0, 0};
     int fft_next = 0;  // the slot the next new size replaces
+    // device blocks of the imaging entry points (imaging.hip: DevBuf), kept between calls: a resident imaging call
+    // (gridhip_do_imaging_dev) then neither allocates nor frees - hipFree synchronises the whole device.  All of a
+    // context's work is ordered on one stream (gridhip_set_stream orders a new one after the old), so a block handed
+    // back by one call may be handed out to the next without waiting.
+    std::vector<std::pair<void *, size_t>> pool_free;
 };
 
 namespace gridhip {

@@ -289,6 +289,8 @@ int gridhip_destroy(gridhip_ctx *ctx)
     Workspace *all[] = {&ctx->recs, &ctx->tables, &ctx->stage, &ctx->blockhist, &ctx->sorted, &ctx->recs_tmp, &ctx->recs_raw, &ctx->ktab, &ctx->aw};
     for (Workspace *w : all)
         if (w->ptr) (void)hipFree(w->ptr);
+    for (auto &b : ctx->pool_free) (void)hipFree(b.first);
+    ctx->pool_free.clear();
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     for (int i = 0; i < gridhip_ctx::EV_RING * 3; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);

@@ -355,16 +355,46 @@ int dev_w_kernel(gridhip_ctx *ctx, double theta, double w, int64_t npixFF, int64
     return GRIDHIP_OK;
 }
 
-// simple device buffer that frees itself; these entry points are not on the timed path
+// Device buffer of one imaging call, drawn from and returned to the context's pool (gridhip_ctx::pool_free): the
+// smallest pooled block of at least the size asked for and at most twice it, else a new one.  Nothing is freed
+// before gridhip_destroy, so the second call of a given shape allocates nothing.
 struct DevBuf {
     void *p = nullptr;
+    size_t cap = 0;
+    gridhip_ctx *owner = nullptr;
     ~DevBuf()
     {
-        if (p) (void)hipFree(p);
+        if (p && owner) owner->pool_free.emplace_back(p, cap);
     }
     int alloc(gridhip_ctx *ctx, size_t bytes)
     {
-        GH_CHECK_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
+        if (bytes < 256) bytes = 256;
+        owner = ctx;
+        int best = -1;
+        for (int i = 0; i < (int)ctx->pool_free.size(); ++i) {
+            const size_t c = ctx->pool_free[i].second;
+            if (c >= bytes && c <= 2 * bytes && (best < 0 || c < ctx->pool_free[best].second)) best = i;
+        }
+        if (best >= 0) {
+            p = ctx->pool_free[best].first;
+            cap = ctx->pool_free[best].second;
+            ctx->pool_free.erase(ctx->pool_free.begin() + best);
+            return GRIDHIP_OK;
+        }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipErrorOutOfMemory && !ctx->pool_free.empty()) {  // give the pooled blocks back and try once more
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+            for (auto &b : ctx->pool_free) (void)hipFree(b.first);
+            ctx->pool_free.clear();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(ctx, e == hipErrorOutOfMemory ? GRIDHIP_ENOMEM : GRIDHIP_EHIP, "hipMalloc(%zu) failed: %s", bytes,
+                        hipGetErrorString(e));
+        }
+        cap = bytes;
         return GRIDHIP_OK;
     }
     template <typename T>
@@ -373,6 +403,18 @@ struct DevBuf {
         return reinterpret_cast<T *>(p);
     }
 };
+
+// inputs / outputs of an imaging call: host arrays (the drop-in forms) or device-resident ones (the _dev forms)
+static int copy_in(gridhip_ctx *ctx, void *d, const void *src, size_t bytes, bool dev)
+{
+    if (bytes) GH_CHECK_HIP(ctx, hipMemcpyAsync(d, src, bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    return GRIDHIP_OK;
+}
+static int copy_out(gridhip_ctx *ctx, void *dst, const void *d, size_t bytes, bool dev)
+{
+    if (bytes) GH_CHECK_HIP(ctx, hipMemcpyAsync(dst, d, bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return GRIDHIP_OK;
+}
 
 static int h2d(gridhip_ctx *ctx, void *d, const void *h, size_t bytes)
 {
@@ -422,7 +464,7 @@ static int dev_wbins(gridhip_ctx *ctx, int64_t n, const double *w, int64_t strid
 template <typename ImgFn>
 static int do_imaging_impl(gridhip_ctx *ctx, double theta, int64_t lam, int64_t n, const double *u, const double *v,
                            const double *w, int64_t stride, const double *vis, double *image, double *psf,
-                           double *pmax, ImgFn imgfn)
+                           double *pmax, bool dev, ImgFn imgfn)
 {
     const int64_t N = haskell_round(theta * (double)lam);
     if (N <= 0) return fail(ctx, GRIDHIP_EINVAL, "theta*lam rounds to %lld", (long long)N);
@@ -440,27 +482,28 @@ static int do_imaging_impl(gridhip_ctx *ctx, double theta, int64_t lam, int64_t 
     GH_CHECK(dtmp.alloc(ctx, cells * 16));
     GH_CHECK(dreal.alloc(ctx, cells * 8));
     GH_CHECK(dmax.alloc(ctx, 8));
-    // slice the columns (src/Gridding.hs:524-526) while uploading
+    // slice the columns (src/Gridding.hs:524-526) while uploading (device-resident inputs: straight from them)
     {
         const size_t span = n > 0 ? (size_t)(n - 1) * stride + 1 : 0;
         DevBuf s0, s1, s2;
-        GH_CHECK(s0.alloc(ctx, span * 8));
-        GH_CHECK(s1.alloc(ctx, span * 8));
-        GH_CHECK(s2.alloc(ctx, span * 8));
-        GH_CHECK(h2d(ctx, s0.p, u, span * 8));
-        GH_CHECK(h2d(ctx, s1.p, v, span * 8));
-        GH_CHECK(h2d(ctx, s2.p, w, span * 8));
-        if (n > 0) {
-            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, s0.as<double>(), stride,
-                               1.0, du.as<double>());
-            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, s1.as<double>(), stride,
-                               1.0, dv.as<double>());
-            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, s2.as<double>(), stride,
-                               1.0, dw.as<double>());
+        const double *su = u, *sv = v, *sw = w;
+        if (!dev) {
+            GH_CHECK(s0.alloc(ctx, span * 8));
+            GH_CHECK(s1.alloc(ctx, span * 8));
+            GH_CHECK(s2.alloc(ctx, span * 8));
+            GH_CHECK(h2d(ctx, s0.p, u, span * 8));
+            GH_CHECK(h2d(ctx, s1.p, v, span * 8));
+            GH_CHECK(h2d(ctx, s2.p, w, span * 8));
+            su = s0.as<double>(), sv = s1.as<double>(), sw = s2.as<double>();
         }
-        GH_CHECK(sync(ctx));
+        if (n > 0) {
+            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, su, stride, 1.0, du.as<double>());
+            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, sv, stride, 1.0, dv.as<double>());
+            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, sw, stride, 1.0, dw.as<double>());
+        }
+        if (!dev) GH_CHECK(sync(ctx));  // (the staging blocks go back to the pool; all later work is stream-ordered after this)
     }
-    GH_CHECK(h2d(ctx, dvis.p, vis, n * 16));
+    GH_CHECK(copy_in(ctx, dvis.p, vis, n * 16, dev));
     if (n > 0) {
         // mirror baselines such that v >= 0 (:531)
         hipLaunchKernelGGL(mirror_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, du.as<double>(),
@@ -507,8 +550,8 @@ static int do_imaging_impl(gridhip_ctx *ctx, double theta, int64_t lam, int64_t 
     hipLaunchKernelGGL(divide_kernel, grid_for(ctx, cells), dim3(256), 0, ctx->stream, (int64_t)cells,
                        dtmp.as<double>(), dmax.as<unsigned long long>());
     GH_CHECK_HIP(ctx, hipGetLastError());
-    if (image) GH_CHECK(d2h(ctx, image, dreal.p, cells * 8));
-    if (psf) GH_CHECK(d2h(ctx, psf, dtmp.p, cells * 8));
+    if (image) GH_CHECK(copy_out(ctx, image, dreal.p, cells * 8, dev));
+    if (psf) GH_CHECK(copy_out(ctx, psf, dtmp.p, cells * 8, dev));
     GH_CHECK(sync(ctx));
     return GRIDHIP_OK;
 }
@@ -908,33 +951,36 @@ int gridhip_aw_imaging(gridhip_ctx *ctx, double theta, int64_t lam, int64_t W, i
 
 // do_imaging, src/Gridding.hs:509-549.  kind selects the ImagingFunction:
 //   0 simple_imaging ; 1 conv_imaging kv (Q, gh, gw, kv) ; 2 w_cache_imaging (wstep, Q=qpx, npixFF, gh=npixKern)
-int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int64_t npixFF, int64_t gh, int64_t gw,
-                       const double *kv, double theta, int64_t lam, int64_t n, const double *u, const double *v,
-                       const double *w, int64_t uv_stride, const double *vis, double *image, double *psf,
-                       double *pmax)
+// dev: every array argument (kv, u, v, w, vis, image, psf) is device-resident; pmax stays a host pointer.
+static int do_imaging_any(gridhip_ctx *ctx, bool dev, int kind, int64_t wstep, int64_t Q, int64_t npixFF, int64_t gh,
+                          int64_t gw, const double *kv, double theta, int64_t lam, int64_t n, const double *u,
+                          const double *v, const double *w, int64_t uv_stride, const double *vis, double *image,
+                          double *psf, double *pmax)
 {
     if (!ctx) return GRIDHIP_EINVAL;
     if (n < 0 || uv_stride < 1 || (n > 0 && (!u || !v || !w || !vis))) return fail(ctx, GRIDHIP_EINVAL, "bad argument");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     if (kind == 0) {
-        return do_imaging_impl(ctx, theta, lam, n, u, v, w, uv_stride, vis, image, psf, pmax,
+        return do_imaging_impl(ctx, theta, lam, n, u, v, w, uv_stride, vis, image, psf, pmax, dev,
                                [&](int64_t N, const double *uu, const double *vv, const double *, const double *vs,
                                    double *g) { return simple_grid_dev(ctx, lam, N, n, uu, vv, vs, g); });
     } else if (kind == 1) {
         if (!kv || Q <= 0 || gh <= 0 || gw <= 0) return fail(ctx, GRIDHIP_EINVAL, "bad kernel");
         DevBuf dk;
-        GH_CHECK(dk.alloc(ctx, (size_t)Q * Q * gh * gw * 16));
-        GH_CHECK(h2d(ctx, dk.p, kv, (size_t)Q * Q * gh * gw * 16));
-        return do_imaging_impl(ctx, theta, lam, n, u, v, w, uv_stride, vis, image, psf, pmax,
+        const double *k = kv;
+        if (!dev) {
+            GH_CHECK(dk.alloc(ctx, (size_t)Q * Q * gh * gw * 16));
+            GH_CHECK(h2d(ctx, dk.p, kv, (size_t)Q * Q * gh * gw * 16));
+            k = dk.as<double>();
+        }
+        return do_imaging_impl(ctx, theta, lam, n, u, v, w, uv_stride, vis, image, psf, pmax, dev,
                                [&](int64_t N, const double *uu, const double *vv, const double *, const double *vs,
-                                   double *g) {
-                                   return conv_grid_dev(ctx, lam, N, Q, gh, gw, dk.as<double>(), n, uu, vv, vs, g);
-                               });
+                                   double *g) { return conv_grid_dev(ctx, lam, N, Q, gh, gw, k, n, uu, vv, vs, g); });
     } else if (kind == 2) {
         if (wstep <= 0) wstep = 2000;
         if (Q <= 0 || npixFF <= 0 || gh <= 0 || gh > npixFF) return fail(ctx, GRIDHIP_EINVAL, "bad kernel options");
         WCache cache;  // built by the image pass, reused by the PSF pass
-        return do_imaging_impl(ctx, theta, lam, n, u, v, w, uv_stride, vis, image, psf, pmax,
+        return do_imaging_impl(ctx, theta, lam, n, u, v, w, uv_stride, vis, image, psf, pmax, dev,
                                [&](int64_t N, const double *uu, const double *vv, const double *ww, const double *vs,
                                    double *g) {
                                    return w_cache_grid_dev(ctx, cache, theta, lam, wstep, Q, npixFF, gh, N, n, uu, vv,
@@ -942,6 +988,54 @@ int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int
                                });
     }
     return fail(ctx, GRIDHIP_EINVAL, "unknown imaging function %d", kind);
+}
+
+int gridhip_do_imaging(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int64_t npixFF, int64_t gh, int64_t gw,
+                       const double *kv, double theta, int64_t lam, int64_t n, const double *u, const double *v,
+                       const double *w, int64_t uv_stride, const double *vis, double *image, double *psf,
+                       double *pmax)
+{
+    return do_imaging_any(ctx, false, kind, wstep, Q, npixFF, gh, gw, kv, theta, lam, n, u, v, w, uv_stride, vis, image,
+                          psf, pmax);
+}
+
+int gridhip_do_imaging_dev(gridhip_ctx *ctx, int kind, int64_t wstep, int64_t Q, int64_t npixFF, int64_t gh, int64_t gw,
+                           const double *kv, double theta, int64_t lam, int64_t n, const double *u, const double *v,
+                           const double *w, int64_t uv_stride, const double *vis, double *image, double *psf,
+                           double *pmax)
+{
+    return do_imaging_any(ctx, true, kind, wstep, Q, npixFF, gh, gw, kv, theta, lam, n, u, v, w, uv_stride, vis, image,
+                          psf, pmax);
+}
+
+// w_cache_imaging with device-resident uvw (wavelengths), vis and N x N grid (overwritten)
+int gridhip_w_cache_imaging_dev(gridhip_ctx *ctx, int64_t wstep, int64_t qpx, int64_t npixFF, int64_t npixKern,
+                                double theta, int64_t lam, int64_t n, const double *u, const double *v, const double *w,
+                                int64_t uv_stride, const double *vis, double *grid)
+{
+    if (!ctx) return GRIDHIP_EINVAL;
+    const int64_t N = haskell_round(theta * (double)lam);
+    if (wstep <= 0) wstep = 2000;
+    if (N <= 0 || n < 0 || uv_stride < 1 || !grid || qpx <= 0 || npixFF <= 0 || npixKern <= 0 || npixKern > npixFF ||
+        (n > 0 && (!u || !v || !w || !vis)))
+        return fail(ctx, GRIDHIP_EINVAL, "bad argument");
+    GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf du, dv, dw;
+    const double *pu = u, *pv = v, *pw = w;
+    if (uv_stride != 1) {  // the (n, 3) matrix: slice its columns
+        GH_CHECK(du.alloc(ctx, n * 8));
+        GH_CHECK(dv.alloc(ctx, n * 8));
+        GH_CHECK(dw.alloc(ctx, n * 8));
+        if (n > 0) {
+            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, u, uv_stride, 1.0, du.as<double>());
+            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, v, uv_stride, 1.0, dv.as<double>());
+            hipLaunchKernelGGL(scale_kernel, grid_for(ctx, n), dim3(256), 0, ctx->stream, n, w, uv_stride, 1.0, dw.as<double>());
+        }
+        pu = du.as<double>(), pv = dv.as<double>(), pw = dw.as<double>();
+    }
+    GH_CHECK_HIP(ctx, hipMemsetAsync(grid, 0, (size_t)N * N * 16, ctx->stream));
+    WCache cache;
+    return w_cache_grid_dev(ctx, cache, theta, lam, wstep, qpx, npixFF, npixKern, N, n, pu, pv, pw, vis, grid);
 }
 
 }  // extern "C"

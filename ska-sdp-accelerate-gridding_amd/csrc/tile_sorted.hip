@@ -72,13 +72,28 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
 {
     extern __shared__ double lds[];
     constexpr int S2 = S * S;
-    constexpr int NSTEP = (S2 + 63) / 64;
-    constexpr int TAIL0 = S2 - (NSTEP - 1) * 64;
+    // Lanes take consecutive taps t = 64 * step + lane of the slice's row-major tap list.
+    constexpr int TAIL0 = S2 - ((S2 + 63) / 64 - 1) * 64;  // taps of the list's last step
     // A last step with 33 or 34 taps keeps 32 of them: an LDS atomic with at most two 16-lane groups active costs
     // 6 cycles instead of 7.  The one or two taps left over are added once per block of 64 records, every lane for
-    // its own record (gridding only; 15x15: 62 -> 60.25 LDS cycles per visibility).
-    constexpr int EXTRA = (!DEGRID && TAIL0 > 32 && TAIL0 <= 34) ? TAIL0 - 32 : 0;
-    constexpr int TAIL = TAIL0 - EXTRA;
+    // its own record (gridding only; 15x15: 62 -> 60.25 LDS cycles per visibility).  Large supports whose list ends
+    // in one or two taps (31x31: 961 = 15 x 64 + 1) drop that step altogether the same way.
+    constexpr int EXTRA = DEGRID ? 0 : (TAIL0 > 32 && TAIL0 <= 34) ? TAIL0 - 32 : (S2 > 256 && TAIL0 <= 2) ? TAIL0 : 0;
+    constexpr int S2E = S2 - EXTRA;                 // taps the steps cover
+    constexpr int NSTEP_ALL = (S2E + 63) / 64;
+    constexpr int TAIL = S2E - (NSTEP_ALL - 1) * 64;
+    // Supports above 16 x 16 (more than four steps): a slice's steps are taken in FP PARTS of at most four, so that a
+    // part's taps fit the registers a tap set has (3 sets x 4 steps x 4 VGPRs).  The unit the walkers rotate through
+    // their tap sets is (run, part): a run's visibilities are accumulated once per part, each time with that part's
+    // taps in registers.  One record per visibility, one tile with the full support's halo, no padding - against
+    // sub-footprints (api.hip), which give every visibility one record per spatial part.  Parts 0 .. REM-1 have KST
+    // steps, the others KST - 1 (all KST when REM = 0); FP = 1 up to 16 x 16.
+    constexpr int FP = (NSTEP_ALL + 3) / 4;
+    constexpr int KST = (NSTEP_ALL + FP - 1) / FP;
+    constexpr int REM = NSTEP_ALL % FP;
+    constexpr int PBASE = NSTEP_ALL / FP;                       // steps of the shorter parts
+    constexpr int NSTEP = KST;                                  // registers of one tap set: NSTEP double2
+    constexpr int LASTS = (REM == 0 ? KST : KST - 1) - 1;       // the list's last step, as a step of the last part
     // With a 32-tap last step, two visibilities of a run share it: lanes 32..63 hold the same 32 taps again and
     // take the second visibility (one full-width instruction pair, 16 cycles, instead of two half-width ones, 24).
     constexpr bool PAIR = !DEGRID && TAIL == 32;
@@ -254,10 +269,15 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
         int t = s * 64 + lane;
-        if (s == NSTEP - 1 && !tail_ok) t = PAIR ? s * 64 + lane - 32 : 0;  // idle lanes (PAIR: the same taps again)
+        if (FP == 1 && s == NSTEP - 1 && !tail_ok) t = PAIR ? s * 64 + lane - 32 : 0;  // idle lanes (PAIR: the same taps again)
         loff[s] = (t / S) * g.ldw + (t % S);
     }
-    const int ttail = tail_ok ? (NSTEP - 1) * 64 + lane : PAIR ? (NSTEP - 1) * 64 + lane - 32 : 0;
+    // the tail step's tap index relative to its part's first tap: lanes without a tap repeat a valid one
+    const int ttail = tail_ok ? LASTS * 64 + lane : PAIR ? LASTS * 64 + lane - 32 : 0;
+    // (FP > 1) this lane's place in a step that starts a row: t = (A + lrow) * S + (B + lcol) for a step whose
+    // first tap is A * S + B; lcol + B may carry into the next row
+    const int lrow = lane / S, lcol = lane - lrow * S;
+    const int lbase0 = lrow * g.ldw + lcol;
 
     // ---- a walker's job: its piece of the sorted list of scratch half `slot` ------------------------------
     // The piece is taken in blocks of 64 records: two coalesced loads bring a block into registers, one

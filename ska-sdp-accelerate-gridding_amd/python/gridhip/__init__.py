@@ -366,8 +366,30 @@ class Context:
                                                    self._ptr(u), self._ptr(v), st, self._ptr(vis), self._ptr(g)))
         return g
 
+    def _uvw_dev(self, uvw):
+        """device-resident baselines: a (u, v, w) tuple of cuda float64 tensors or an (n, 3) cuda tensor"""
+        import torch
+        if isinstance(uvw, (tuple, list)):
+            u, v, w = (x.to(torch.float64).contiguous() for x in uvw)
+            return u, v, w, 1
+        m = uvw.to(torch.float64).contiguous()
+        return m[:, 0], m[:, 1], m[:, 2], 3
+
     def w_cache_imaging(self, kernops, theta, lam, uvw, src, vis):
-        """:399-449 ; kernops = dict(wstep=, qpx=, npixFF=, npixKern=) as KernelOptions (:30-38)"""
+        """:399-449 ; kernops = dict(wstep=, qpx=, npixFF=, npixKern=) as KernelOptions (:30-38).
+        torch cuda tensors take the device-resident form (gridhip_w_cache_imaging_dev) and return a cuda tensor."""
+        if _is_torch(vis):
+            import torch
+            u, v, w, st = self._uvw_dev(uvw)
+            vis = vis.to(torch.complex128).contiguous()
+            N = self.image_size(theta, lam)
+            g = torch.empty((N, N), dtype=torch.complex128, device=vis.device)
+            self._use_torch_stream()
+            self._check(self._lib.gridhip_w_cache_imaging_dev(
+                self._h, int(kernops.get("wstep") or 2000), int(kernops["qpx"]), int(kernops["npixFF"]),
+                int(kernops["npixKern"]), float(theta), int(lam), int(vis.shape[0]), self._ptr(u), self._ptr(v),
+                self._ptr(w), st, self._ptr(vis), self._ptr(g)))
+            return g
         u, v, w, st = self._uvw(uvw)
         vis = self._np(vis, np.complex128)
         N = self.image_size(theta, lam)
@@ -380,16 +402,27 @@ class Context:
 
     def do_imaging(self, theta, lam, uvw, a1, a2, t, f, vis, imgfn):
         """:509-549 -> (image, psf, pmax).  imgfn = ("simple",) | ("conv", kv) | ("w_cache", kernops);
-        a1, a2, t, f (src) are accepted for signature parity and unused by these imaging functions."""
-        u, v, w, st = self._uvw(uvw)
-        vis = self._np(vis, np.complex128)
+        a1, a2, t, f (src) are accepted for signature parity and unused by these imaging functions.
+        torch cuda tensors (uvw, vis, and kv for "conv") take the device-resident form (gridhip_do_imaging_dev):
+        nothing crosses PCIe, image and psf come back as cuda tensors."""
+        dev = _is_torch(vis)
         N = self.image_size(theta, lam)
-        img = np.empty((N, N), dtype=np.float64)
-        psf = np.empty((N, N), dtype=np.float64)
+        if dev:
+            import torch
+            u, v, w, st = self._uvw_dev(uvw)
+            vis = vis.to(torch.complex128).contiguous()
+            img = torch.empty((N, N), dtype=torch.float64, device=vis.device)
+            psf = torch.empty((N, N), dtype=torch.float64, device=vis.device)
+            self._use_torch_stream()
+        else:
+            u, v, w, st = self._uvw(uvw)
+            vis = self._np(vis, np.complex128)
+            img = np.empty((N, N), dtype=np.float64)
+            psf = np.empty((N, N), dtype=np.float64)
         pmax = C.c_double()
         kind, wstep, Q, npixFF, gh, gw, kv = 0, 0, 0, 0, 0, 0, None
         if imgfn[0] == "conv":
-            kv = self._np(imgfn[1], np.complex128)
+            kv = imgfn[1].to(vis.dtype).contiguous() if dev else self._np(imgfn[1], np.complex128)
             kind, (Q, _, gh, gw) = 1, kv.shape
         elif imgfn[0] == "w_cache":
             ko = imgfn[1]
@@ -397,9 +430,10 @@ class Context:
             gw = gh
         elif imgfn[0] != "simple":
             raise ValueError("unknown imaging function")
-        self._check(self._lib.gridhip_do_imaging(self._h, kind, wstep, Q, npixFF, gh, gw, self._ptr(kv), float(theta),
-                                                 int(lam), len(vis), self._ptr(u), self._ptr(v), self._ptr(w), st,
-                                                 self._ptr(vis), self._ptr(img), self._ptr(psf), C.byref(pmax)))
+        fn = self._lib.gridhip_do_imaging_dev if dev else self._lib.gridhip_do_imaging
+        self._check(fn(self._h, kind, wstep, Q, npixFF, gh, gw, self._ptr(kv), float(theta), int(lam), int(vis.shape[0]),
+                       self._ptr(u), self._ptr(v), self._ptr(w), st, self._ptr(vis), self._ptr(img), self._ptr(psf),
+                       C.byref(pmax)))
         return img, psf, pmax.value
 
 

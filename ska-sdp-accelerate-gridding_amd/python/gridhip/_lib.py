@@ -66,6 +66,9 @@ SIGNATURES = {
                                 vp, vp]),
     "gridhip_do_imaging": (ci, [vp, ci, i64, i64, i64, i64, i64, vp, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp,
                                 vp, C.POINTER(C.c_double)]),
+    "gridhip_do_imaging_dev": (ci, [vp, ci, i64, i64, i64, i64, i64, vp, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp,
+                                    vp, C.POINTER(C.c_double)]),
+    "gridhip_w_cache_imaging_dev": (ci, [vp, i64, i64, i64, i64, C.c_double, i64, i64, vp, vp, vp, i64, vp, vp]),
     "gridhip_comm_create": (ci, [ci, C.POINTER(ci), C.POINTER(vp)]),
     "gridhip_comm_unique_id": (ci, [vp]),
     "gridhip_comm_create_rank": (ci, [vp, ci, ci, vp, C.POINTER(vp)]),

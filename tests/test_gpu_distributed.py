@@ -175,7 +175,7 @@ def test_bench_multi_gpu_branch_with_one_rank(collective):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(GRIDHIP_BENCH_FORCE_DIST="1", MASTER_PORT="29535")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nvis",
-                          "3000000", "--no-cpu", "--collective", collective], capture_output=True, text=True,
+                          "3000000", "--no-cpu", "--collective", collective, "--reserve-cus", "16"], capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-4000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

@@ -119,3 +119,55 @@ def test_do_imaging(ctx, kind):
     assert abs(pmax - rpmax) / abs(rpmax) < TOL
     assert rel(psf, rpsf) < TOL and abs(psf.max() - 1.0) < 1e-12
     assert rel(img, rimg) < TOL
+
+
+@pytest.mark.parametrize("kind", ["simple", "w_cache"])
+def test_do_imaging_at_the_drivers_size_host_and_resident(ctx, kind):
+    """do_imaging (src/Gridding.hs:509-549) at the size the reference's driver images at - theta = 0.008, lam = 300000,
+    N = round(theta * lam) = 2400 (src/ImageDataset.hs:32-33; not a power of two: hipFFT's general path) - with
+    1.2 x 10^5 visibilities and, for w_cache_imaging, 15 x 15 kernels generated on the device, against the numpy oracle;
+    and the device-resident form (gridhip_do_imaging_dev: torch cuda tensors in and out, (n, 3) uvw matrix) against
+    the host form.  Parity unpinned by the reference (it records no image)."""
+    import torch
+    theta, lam = 0.008, 300000
+    N = ctx.image_size(theta, lam)
+    assert N == 2400
+    n = 120_000
+    u, v, w, vis = _vis(31, n, 0.47 * lam, 700.0)
+    ko = dict(wstep=100, qpx=2, npixFF=64, npixKern=15)
+    if kind == "simple":
+        fn = lambda th, la, uu, vv, ww, vs: P.grid(np.zeros((N, N), complex), uu / la, vv / la, vs)
+        spec = ("simple",)
+    else:
+        fn = lambda th, la, uu, vv, ww, vs: P.w_cache_imaging(th, la, uu, vv, ww, vs, 100, 2, 64, 15)[0]
+        spec = ("w_cache", ko)
+    rimg, rpsf, rpmax = P.do_imaging(theta, lam, u, v, w, vis, fn)
+    img, psf, pmax = ctx.do_imaging(theta, lam, (u, v, w), None, None, None, 1.0e8, vis, spec)
+    assert abs(pmax - rpmax) / abs(rpmax) < TOL
+    assert rel(psf, rpsf) < TOL and abs(psf.max() - 1.0) < 1e-12
+    assert rel(img, rimg) < TOL
+    dev = torch.device("cuda:0")
+    uvw = torch.from_numpy(np.stack([u, v, w], 1)).to(dev)
+    tvis = torch.from_numpy(vis).to(dev)
+    for _ in range(2):  # (the second call draws every block from the context's pool)
+        dimg, dpsf, dpmax = ctx.do_imaging(theta, lam, uvw, None, None, None, 1.0e8, tvis, spec)
+        torch.cuda.synchronize()
+        assert dimg.is_cuda and dpsf.is_cuda
+        assert abs(dpmax - rpmax) / abs(rpmax) < TOL
+        assert rel(dimg.cpu().numpy(), rimg) < TOL and rel(dpsf.cpu().numpy(), rpsf) < TOL
+    assert torch.equal(tvis.cpu(), torch.from_numpy(vis))  # inputs are not modified (mirror works on a copy)
+    assert ctx.get_option("errors") == 0
+
+
+def test_w_cache_imaging_resident(ctx):
+    import torch
+    theta, lam = 0.05, 2560
+    u, v, w, vis = _vis(7, 3000, 1200, 900)
+    ko = dict(wstep=100, qpx=2, npixFF=64, npixKern=15)
+    ref = ctx.w_cache_imaging(ko, theta, lam, (u, v, w), None, vis)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    got = ctx.w_cache_imaging(ko, theta, lam, (t(u), t(v), t(w)), None, t(vis))
+    got3 = ctx.w_cache_imaging(ko, theta, lam, t(np.stack([u, v, w], 1)), None, t(vis))
+    torch.cuda.synchronize()
+    assert rel(got.cpu().numpy(), ref) < 1e-13 and rel(got3.cpu().numpy(), ref) < 1e-13

@@ -2,11 +2,12 @@
 """What does the "reserve_cus" option cost the tile kernel on one GPU, and does a kernel queued on another stream
 really start beside the persistent tile kernel once CUs are left free?
 
-The stand-in for the collective is a device-to-device copy of the rows a mirrored 4096^2 grid reduces (137 MB read +
-137 MB written; an RCCL all-reduce kernel is, like it, a few work-groups that stream memory), enqueued on a side stream
-right after the tile kernel has been launched.  Reported per k: the cfg3 step alone, the step with the copy beside it,
-and when the copy finished relative to the step's start - "copy_end < step_end" means it ran beside the tile kernel
-instead of after it.  usage: python tools/reserve_cus_probe.py [cfg3|cfg5]"""
+The stand-in for the collective is a device-to-device copy of the rows a mirrored 4096^2 grid reduces (135 MB read +
+135 MB written; an RCCL all-reduce kernel is, like it, a few work-groups that stream memory), enqueued on a side stream
+behind a spin kernel that holds it back until the tile kernel is 3 ms into its run (a plan: the pass is the tile
+kernel alone, no pre-pass the copy could slip in beside).  Reported per k: the pass alone, the pass with the copy
+beside it, and when the copy finished relative to the pass's start - "copy_end < pass_end" means it ran beside the
+tile kernel instead of after it.  usage: python tools/reserve_cus_probe.py [cfg3|cfg5]"""
 import os
 import sys
 
@@ -33,8 +34,21 @@ side = torch.cuda.Stream()
 ev = lambda: torch.cuda.Event(enable_timing=True)
 
 
+plan = ctx.plan((N, N), tuple(gcf.shape), (u, v, None), wb)
+
+
 def step():
-    ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+    plan.grid(gcf, G, vis)
+
+
+# spin kernel: how many cycles are 3 ms?
+torch.cuda.synchronize()
+a0, a1 = ev(), ev()
+a0.record()
+torch.cuda._sleep(10_000_000)
+a1.record()
+torch.cuda.synchronize()
+SPIN = int(10_000_000 * 3.0 / a0.elapsed_time(a1))
 
 
 print(f"# {wl}: {n} vis, {N}^2 grid, {S}x{S}; stand-in collective: copy of rows [{y0}, {N}) = {src.numel() * 16 / 1e6:.0f} MB")
@@ -46,14 +60,14 @@ with torch.cuda.stream(side):
     b.record()
 torch.cuda.synchronize()
 print(f"copy alone: {a.elapsed_time(b):.3f} ms")
-print("reserve_cus  step_alone_ms  kernel_alone_ms  step_with_copy_ms  copy_end_after_step_start_ms  copy_ran_beside")
+print("reserve_cus  pass_alone_ms  pass_with_copy_ms  copy_start_ms  copy_end_ms  copy_ran_beside")
 for k in (0, 4, 8, 16, 32, 64):
     ctx.set_option("reserve_cus", k)
     ctx.enable_timing(True)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    alone, kern = [], []
+    alone = []
     for _ in range(5):
         t0, t1 = ev(), ev()
         t0.record()
@@ -61,20 +75,23 @@ for k in (0, 4, 8, 16, 32, 64):
         t1.record()
         torch.cuda.synchronize()
         alone.append(t0.elapsed_time(t1))
-        kern.append(ctx.last_timing()[2])
-    both, cend = [], []
+    both, cbeg, cend = [], [], []
     for _ in range(5):
-        t0, t1, c1 = ev(), ev(), ev()
+        t0, t1, c0, c1 = ev(), ev(), ev(), ev()
         t0.record()
+        side.wait_event(t0)
         step()
         t1.record()
         with torch.cuda.stream(side):
+            torch.cuda._sleep(SPIN)  # the "collective" is issued 3 ms into the tile kernel
+            c0.record()
             dst.copy_(src)
             c1.record()
         torch.cuda.synchronize()
         both.append(t0.elapsed_time(t1))
+        cbeg.append(t0.elapsed_time(c0))
         cend.append(t0.elapsed_time(c1))
     med = lambda x: sorted(x)[len(x) // 2]
-    print(f"{k:11d}  {med(alone):13.3f}  {med(kern):15.3f}  {med(both):17.3f}  {med(cend):28.3f}  {'yes' if med(cend) < med(both) - 0.5 else 'no'}",
+    print(f"{k:11d}  {med(alone):13.3f}  {med(both):17.3f}  {med(cbeg):13.3f}  {med(cend):11.3f}  {'yes' if med(cend) < med(both) - 0.5 else 'no'}",
           flush=True)
 ctx.set_option("reserve_cus", 0)
