@@ -72,7 +72,7 @@ def parse_args(argv=None):
                     help="auto: the stream is mirrored (v >= 0), so only the rows it can touch are reduced (half the bytes)")
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="compute units the persistent tile kernel leaves free for the collective's kernel "
-                         "(-1 = auto: 16 when N > 1, else 0)")
+                         "(-1 = auto: 32 when N > 1 - one per shader engine of every XCD, what lets a many-work-group kernel start beside it, profiles/r03_reserve_cus.txt - else 0)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EEDC0DE)
     ap.add_argument("--opt", action="append", default=[], help="gridhip option key=value (tile, block, chunk, wgroups, variant, sort)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -133,16 +133,20 @@ def compulsory_bytes_per_vis(n, N, W, Q, S):
 def lds_atomic_cycles_per_vis(S):
     """LDS cycles the accumulate loop of the tap-reusing tile kernel needs per visibility: two ds_add_f64 (re, im)
     per step of 64 taps, 8 cycles per 64-lane instruction, 7 with three 16-lane groups active, 6 with two or fewer
-    (measured: tools/micro/lds_atomic.hip, profiles/r01_lds_atomic_microbench.txt)."""
+    (measured: tools/micro/lds_atomic.hip, profiles/r01_lds_atomic_microbench.txt).  Mirrors the kernel's own
+    constants (tile_sorted.hip: TAIL0, EXTRA, NSTEP_ALL, TAIL, PAIR); supports above 16 x 16 take their steps in
+    parts of at most four, which does not change the count."""
     taps = S * S
-    full, tail = divmod(taps, 64)
-    cyc = full * 2 * 8
-    if 32 < tail <= 34:  # the last step keeps 32 taps and serves two visibilities of a run at once (a lone one
-        # pays 2 x 6 cycles for it); the other taps go once per block of 64 records
-        cyc += 2 * 8 / 2 + (tail - 32) * 2 * 8 / 64
-    elif tail:
-        cyc += 2 * (6 if tail <= 32 else 7 if tail <= 48 else 8)
-    return cyc
+    tail0 = taps - ((taps + 63) // 64 - 1) * 64
+    # a last step of 33 or 34 taps keeps 32 (two visibilities of a run then share it: one full-width instruction pair
+    # for both); a last step of one or two taps (supports above 16) disappears; the taps left over go once per block
+    # of 64 records, every lane for its own record
+    extra = tail0 - 32 if 32 < tail0 <= 34 else tail0 if (taps > 256 and tail0 <= 2) else 0
+    covered = taps - extra
+    nstep = (covered + 63) // 64
+    tail = covered - (nstep - 1) * 64
+    last = 2 * 8 / 2 if (tail == 32 and extra) else 2 * (6 if tail <= 32 else 7 if tail <= 48 else 8)
+    return (nstep - 1) * 16 + last + extra * 2 * 8 / 64
 
 
 def csrc_fingerprint():
@@ -490,7 +494,7 @@ def main():
         ctx.set_option(k, int(val))
     if aw:
         ctx.set_option("aw_cache", args.aw_cache)
-    reserve = args.reserve_cus if args.reserve_cus >= 0 else (16 if world > 1 else 0)
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (32 if world > 1 else 0)
     if reserve:
         ctx.set_option("reserve_cus", reserve)
 

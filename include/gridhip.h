@@ -100,13 +100,24 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               remaining CU, so that a collective queued on another stream (RCCL's kernel, a copy) finds CUs to start
  *               on while the tile kernel runs instead of waiting ~10 ms for it to end; costs the tile kernel
  *               k / num_cu of its throughput (profiles/r03_reserve_cus.txt)
+ *   "bigtile"   the tap-reusing kernel's tile uses all of the LDS (65 x 110 cells at 15 x 15 instead of 65 x 89): a
+ *               quarter more visibilities per kernel slice and work item, for an address add per tap step; pays
+ *               where items are sparse (fewer than two visibilities per slice and item), not where the LDS atomic
+ *               unit binds.  0 = auto (sparse streams of at least 2^22 visibilities), 1 = on, 2 = off
+ *   "subfoot"   1 = supports 17..32 take the sub-footprint path (one record per spatial part of the kernel, as
+ *               supports above 32 and non-square kernels always do) instead of the tap-reusing kernel's own parts of
+ *               the tap list (one record per visibility): kept for comparison runs
  *   "wtable"    which table of walker weights the tap-reusing kernel uses: 0 = auto, 1 = flat, 2 = steep (tile_sorted.hip)
  *   "rec_bits"  TEST HOOK: pretend the 64-bit record word has this many bits (16..63), so that small calls take the
  *               path that grids a call in several parts (taken for real above 2^50 slices x visibilities);
  *               100 + t: widen the record's kernel-slice field until its fields take t <= 64 bits
  *   ("dbg", the ablation / profiling switch of tuning runs, exists only in the tuning build of the library,
  *   `make -C csrc tuning` -> lib/libgridhip_tuning.so; the shipped library rejects the key)
- * Read-only (gridhip_get_option): "errors" = internal consistency failures counted by the last tile-kernel
+ * Read-only (gridhip_get_option): "last_path" = which gridder the last convgrid / convgrid2 / degrid2 / plan call used:
+ * 1 = the tap-reusing tile kernel (square supports 5..32 with enough visibilities per work item), 2 = the same through
+ * sub-footprints (other shapes: one record per spatial part of the kernel), 3 = the general tile kernel (small
+ * problems, and the sizes listed under "Limits" below: 2 - 3 x slower per visibility at scale), 4 = direct
+ * global-atomic scatter; "errors" = internal consistency failures counted by the last tile-kernel
  * launch (expected 0); "clock_khz" = shader clock held during the last tap-reusing tile kernel (in-kernel
  * s_memtime / s_memrealtime stamps); "prof0".."prof31" = cycle counters of a dbg=16 launch of the tuning build (tools/phase_profile.py).
  */
@@ -115,6 +126,14 @@ int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value);
 /* Visibilities skipped by the last gridding call because `wbin` was outside [0,W) (the
  * reference would read the kernel out of range).  Synchronises the stream. */
 int gridhip_last_dropped(gridhip_ctx *ctx, int64_t *dropped);
+
+/* ---- Limits ------------------------------------------------------------------------------------
+ * Per call: n < 2^31 - 256 visibilities (GRIDHIP_EUNSUPPORTED above; cut the stream), H, Wd <= 2^30, W * Q * Q <= 2^30,
+ * gh, gw <= 1024.  A kernel that is not a square of side 5..32 is gridded as P = py * px sub-footprints, one binned
+ * record per part, which needs n * P < 2^31 - 256 and W * Q * Q * P < 2^30: a call beyond either takes the general
+ * tile kernel instead (read-only option "last_path" = 3 says so; nothing is lost but speed) - cut the stream into
+ * calls of fewer visibilities to stay on the fast path.  Slices x visibilities above 2^50 are gridded in several
+ * parts internally.  degrid2 has no direct form: a support too large for an LDS tile is GRIDHIP_EUNSUPPORTED. */
 
 /* ---- gridders: host pointers (drop-in) -------------------------------------------------- */
 

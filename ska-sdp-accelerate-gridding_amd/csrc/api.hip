@@ -67,10 +67,11 @@ __global__ void __launch_bounds__(256) pad_kernels_kernel(Geom g, int64_t nslice
 namespace gridhip {
 
 // How a kernel shape the tap-reusing tile kernel has no instantiation for is cut into square parts it has one for:
-// py x px parts of side sub = max(ceil(gh / py), ceil(gw / px)), the fewest parts with sub <= 16.
-static bool choose_parts(int64_t gh, int64_t gw, int *py, int *px, int *sub)
+// py x px parts of side sub = max(ceil(gh / py), ceil(gw / px)), the fewest parts with sub <= side (32: the largest
+// square the tap-reusing kernel is instantiated for; 16 under option "subfoot", round 2's cut).
+static bool choose_parts(int64_t gh, int64_t gw, int side, int *py, int *px, int *sub)
 {
-    const int y = (int)((gh + 15) / 16), x = (int)((gw + 15) / 16);
+    const int y = (int)((gh + side - 1) / side), x = (int)((gw + side - 1) / side);
     const int sy = (int)((gh + y - 1) / y), sx = (int)((gw + x - 1) / x);
     int sb = sy > sx ? sy : sx;
     if (sb < 5) sb = 5;  // (smallest instantiation)
@@ -100,7 +101,10 @@ int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64
     if (rc == GRIDHIP_OK) {
         // sort: 0 = auto (on when a work item holds enough visibilities for slices to repeat), 1 = on, 2 = off
         const bool want = ctx->opt.sort == 1 || (ctx->opt.sort == 0 && n / (int64_t)p->g.nbins >= 256);
-        p->sorted = want && sorted_plan(ctx, p->g, p->block, &p->nkeys, &p->batch, &p->lds_sorted);
+        // option "subfoot" = 1: supports above 16 go through sub-footprints (one record per spatial part) as in round 2,
+        // instead of the tile kernel's parts of the tap list (one record per visibility) - kept for comparison runs
+        const bool old_parts = ctx->opt.subfoot == 1 && gh > 16;
+        p->sorted = want && !old_parts && sorted_plan(ctx, p->g, p->block, &p->nkeys, &p->batch, &p->lds_sorted);
         // a sorted work item may span several LDS batches; keep it big enough to flush each tile once
         if (p->sorted) {
             p->g.chunk = p->batch;
@@ -111,7 +115,8 @@ int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64
         return rc;
     // sub-footprints: supports above 16 and non-square kernels as P records of a small square support each
     int py, px, sub;
-    if (ctx->opt.sort != 2 && (gh != gw || gh > 16 || gh < 5) && choose_parts(gh, gw, &py, &px, &sub) &&
+    const int side = ctx->opt.subfoot == 1 ? 16 : 32;
+    if (ctx->opt.sort != 2 && (gh != gw || gh > side || gh < 5) && choose_parts(gh, gw, side, &py, &px, &sub) &&
         n * (int64_t)(py * px) < (int64_t)0x7fffff00 && W * Q * Q * (int64_t)(py * px) < ((int64_t)1 << 30)) {
         Prep q;
         const int P = py * px;
@@ -145,6 +150,7 @@ int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64
 
 int tile_kernels(gridhip_ctx *ctx, const Prep &p, const double *gcf, const double **out)
 {
+    ctx->last_path = p.direct ? 4 : !p.sorted ? 3 : p.g.P > 1 || p.g.fgh != p.g.gh || p.g.fgw != p.g.gw ? 2 : 1;
     *out = gcf;
     if (p.g.P == 1 && p.g.fgh == p.g.gh && p.g.fgw == p.g.gw) return GRIDHIP_OK;
     const int64_t nsl = (int64_t)p.g.W * p.g.Q * p.g.Q;
@@ -210,6 +216,7 @@ int gridhip_convgrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid,
         return GRIDHIP_OK;
     }
     if (p.direct) {
+        ctx->last_path = 4;
         mark(ctx, 0);
         mark(ctx, 1);
         GH_CHECK(launch_direct_grid(ctx, H, Wd, grid, n, W, Q, gh, gw, gcf, u, v, uv_stride, wbin, vis));
@@ -264,8 +271,9 @@ int gridhip_degrid2_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, const double *g
     GH_CHECK(ws_reserve(ctx, ctx->recs, (size_t)(p.nrec > 0 ? p.nrec : 1) * sizeof(RecWord)));
     mark(ctx, 0);
     // visibilities with no tap inside the grid (or an out-of-range wbin) predict 0: the counting sweep writes those
-    // zeros.  Sub-footprints sum a visibility's parts with atomics, so there the whole array starts from zero.
-    const bool parts = p.g.P > 1 || ctx->opt.fault_inject > 0;  // (the test hook loses records: clear as well)
+    // zeros.  Sub-footprints, and supports above 16 x 16 in the tap-reusing kernel (parts of the tap list), sum a
+    // visibility's parts with atomics, so there the whole array starts from zero.
+    const bool parts = p.g.P > 1 || (p.sorted && p.g.gh > 16) || ctx->opt.fault_inject > 0;  // (the test hook loses records: clear as well)
     if (n > 0 && parts) GH_CHECK_HIP(ctx, hipMemsetAsync(vis_out, 0, (size_t)n * 16, ctx->stream));
     const double *tk = gcf;
     GH_CHECK(tile_kernels(ctx, p, gcf, &tk));

@@ -60,13 +60,18 @@ __global__ void aw_pairs_kernel(int64_t n, int64_t A, const int64_t *__restrict_
 
 // pairk[slot] = convolve2d(akerns[a1], akerns[a2]) for every pair that occurs (one work-group per pair at a time)
 __global__ void aw_pair_kernel(int64_t A, int S, const double2 *__restrict__ akerns, const int32_t *__restrict__ pairlist,
-                               const int32_t *__restrict__ counters, int32_t cap, double2 *__restrict__ pairk)
+                               const int32_t *__restrict__ counters, int32_t cap, double2 *__restrict__ pairk,
+                               int32_t *__restrict__ errors)
 {
     extern __shared__ double2 sm[];
     const int npairs = min(counters[0], cap);
     double2 *la = sm, *lb = sm + S * S;
     for (int s = blockIdx.x; s < npairs; s += gridDim.x) {
-        const int64_t pq = pairlist[s];
+        int64_t pq = pairlist[s];
+        if (pq < 0 || pq >= A * A) {  // (cannot happen: aw_pairs_kernel wrote it)
+            pq = 0;
+            if (threadIdx.x == 0) atomicAdd(errors, 1);
+        }
         const int64_t p = pq / A, q = pq - p * A;
         __syncthreads();
         for (int t = threadIdx.x; t < S * S; t += blockDim.x) {
@@ -149,17 +154,41 @@ __global__ void aw_kid_kernel(int64_t n, const int32_t *__restrict__ hid, int32_
 
 // ---- 3. kernels of the distinct keys: table[id] = conj(convolve2d(pairk[pair], wkerns[wslice]))
 // generic support: one work-group per key at a time
+// Nothing read from memory becomes an address before it is in range (the rule of the tile kernels, tile_common.h):
+// a key names a pair slot below `npair` and a w-kernel slice below `nslice`; anything else (a stale or overwritten
+// table entry - round 2 saw one abort the process) is brought into range and counted in *errors.
+__device__ __forceinline__ void aw_key_operands(unsigned long long key, int64_t npair, int64_t nslice, size_t *ia, size_t *ib,
+                                                int *bad)
+{
+    unsigned long long a = key >> 30, b = key & 0x3fffffffull;
+    if (a >= (unsigned long long)npair) {
+        a = 0;
+        ++*bad;
+    }
+    if (b >= (unsigned long long)nslice) {
+        b = 0;
+        ++*bad;
+    }
+    *ia = (size_t)a;
+    *ib = (size_t)b;
+}
+
 __global__ void aw_build_generic_kernel(int S, const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
                                         const unsigned long long *__restrict__ ukey, const int32_t *__restrict__ counters,
-                                        int which, int32_t fixed_count, int32_t cap, double2 *__restrict__ table)
+                                        int which, int32_t fixed_count, int32_t cap, double2 *__restrict__ table,
+                                        int64_t npair_cap, int64_t nslice, int32_t *__restrict__ errors)
 {
     extern __shared__ double2 sm[];
     const int nk = min(which >= 0 ? counters[which] : fixed_count, cap);
+    const int64_t npair = min((int64_t)counters[0], npair_cap);
     double2 *la = sm, *lb = sm + S * S;
     for (int id = blockIdx.x; id < nk; id += gridDim.x) {
-        const unsigned long long key = ukey[id];
-        const double2 *pk = pairk + (size_t)(key >> 30) * S * S;
-        const double2 *wk = wkerns + (size_t)(key & 0x3fffffffull) * S * S;
+        size_t ia, ib;
+        int bad = 0;
+        aw_key_operands(ukey[id], npair, nslice, &ia, &ib, &bad);
+        if (bad && threadIdx.x == 0) atomicAdd(errors, bad);
+        const double2 *pk = pairk + ia * S * S;
+        const double2 *wk = wkerns + ib * S * S;
         __syncthreads();
         for (int t = threadIdx.x; t < S * S; t += blockDim.x) {
             la[t] = pk[t];
@@ -184,7 +213,8 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
                                                        const unsigned long long *__restrict__ ukey,
                                                        const int32_t *__restrict__ pairlist, int64_t A,
                                                        const int32_t *__restrict__ counters, int which, int32_t fixed_count,
-                                                       int32_t cap, double2 *__restrict__ table)
+                                                       int32_t cap, double2 *__restrict__ table, int64_t npair_cap,
+                                                       int64_t nslice, int32_t *__restrict__ errors)
 {
     constexpr int C = S / 2, PB = S + C, S2 = S * S, BSZ = C + S * PB;  // padded slice: C zeros, then rows of S values + C zeros
     static_assert(S <= 16, "one 16-lane row per kernel");
@@ -203,17 +233,20 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
     for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
         const int64_t id = grp * 4 + q;
         const bool have = id < nk;
-        size_t ia = 0, ib = 0;  // which S x S arrays are convolved
+        size_t ia = 0, ib = 0;  // which S x S arrays are convolved (brought into range before they become addresses)
         if (have) {
+            int bad = 0;
             if (PAIR) {
-                const int64_t pq = pairlist[id];
+                int64_t pq = pairlist[id];
+                if (pq < 0 || pq >= A * A) {
+                    pq = 0;
+                    ++bad;
+                }
                 ia = (size_t)(pq / A);
                 ib = (size_t)(pq - (int64_t)ia * A);
-            } else {
-                const unsigned long long key = ukey[id];
-                ia = (size_t)(key >> 30);
-                ib = (size_t)(key & 0x3fffffffull);
-            }
+            } else
+                aw_key_operands(ukey[id], min((int64_t)counters[0], npair_cap), nslice, &ia, &ib, &bad);
+            if (bad && x == 0) atomicAdd(errors, bad);
         }
         const double2 *pk = pairk + ia * S2;
         const double2 *wk = wkerns + ib * S2;
@@ -285,31 +318,38 @@ __global__ void aw_relabel_kernel(Geom g, RecWord *__restrict__ recs, const int3
     }
 }
 
-// [30] += [0]: the drops of one batch's binning join the call's total; [28] += the batch's distinct kernels
+// [30] += [0]: the drops of one batch's binning join the call's total, [31] += [2] its internal errors (every batch's
+// binning clears [0..2]; the kernel builders count theirs in [31] directly); [28] += the batch's distinct kernels
 __global__ void aw_account_kernel(int32_t *__restrict__ scalars, const int32_t *__restrict__ counters, int cache, int32_t m)
 {
     scalars[30] += scalars[0];
+    scalars[31] += scalars[2];
     scalars[28] += cache ? counters[1] : m;
     scalars[29] += m;
 }
-__global__ void aw_finish_kernel(int32_t *__restrict__ scalars) { scalars[0] = scalars[30]; }
+__global__ void aw_finish_kernel(int32_t *__restrict__ scalars)
+{
+    scalars[0] = scalars[30];
+    scalars[2] = scalars[31];
+}
 
 }  // namespace gridhip
 
 using namespace gridhip;
 
 namespace {
+inline bool cache_on(const gridhip_ctx *ctx) { return ctx->opt.aw_cache != 0; }
 template <int S, bool PAIR>
 int launch_build(gridhip_ctx *ctx, const double2 *wk, const double2 *pairk, const unsigned long long *ukey,
                  const int32_t *pairlist, int64_t A, const int32_t *counters, int which, int32_t fixed, int32_t cap,
-                 double2 *table)
+                 double2 *table, int64_t npair_cap, int64_t nslice)
 {
     constexpr int C = S / 2, PB = S + C, BSZ = C + S * PB;
     const size_t lds = (size_t)16 * (S * S + BSZ) * sizeof(double2);
     GH_CHECK(raise_lds(ctx, aw_build_kernel<S, PAIR>));
     // one work-group (four waves, one per SIMD) per CU; the loop strides over the entries
     hipLaunchKernelGGL((aw_build_kernel<S, PAIR>), dim3(ctx->num_cu), dim3(256), lds, ctx->stream, wk, pairk, ukey, pairlist, A,
-                       counters, which, fixed, cap, table);
+                       counters, which, fixed, cap, table, npair_cap, nslice, ctx->d_scalars + 31);
     return GRIDHIP_OK;
 }
 }  // namespace
@@ -329,13 +369,18 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
     if (S > 63 || A > 46340 || n > (int64_t)0x7fffff00 || W * Q * Q >= ((int64_t)1 << 30))
         return fail(ctx, GRIDHIP_EUNSUPPORTED, "shape outside aw limits");
     GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    // [0] dropped, [2] errors, [28] distinct kernels built, [29] visibilities keyed, [30] dropped so far (batches)
+    // [0] dropped, [2] errors, [28] distinct kernels built, [29] visibilities keyed, [30] dropped so far (batches),
+    // [31] errors so far
     GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 4 * sizeof(int32_t), ctx->stream));
-    GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 28, 0, 3 * sizeof(int32_t), ctx->stream));
+    GH_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 28, 0, 4 * sizeof(int32_t), ctx->stream));
     if (n == 0) return GRIDHIP_OK;
     const size_t S2 = (size_t)S * S, pairs = (size_t)A * A;
     const int cache = ctx->opt.aw_cache != 0;
-    const int64_t batch = n < ((int64_t)1 << 22) ? n : ((int64_t)1 << 22);  // 4M kernels x 3.6 KB = 15 GB at 15x15
+    // The table of kernels is sized for the batch whatever the de-duplication finds (nothing is read back inside a
+    // call): 2^20 visibilities per batch with the cache (3.8 GB of table at 15 x 15; the 10^6-visibility benchmark is
+    // one batch), 2^22 without it, where every visibility has a kernel of its own anyway (15 GB).
+    const int64_t bcap = cache_on(ctx) ? ((int64_t)1 << 20) : ((int64_t)1 << 22);
+    const int64_t batch = n < bcap ? n : bcap;
     const int32_t pair_cap = (int32_t)(pairs < (size_t)n ? pairs : (size_t)n);
     uint32_t hslots = 1024;
     while (hslots < 2 * (uint64_t)batch) hslots <<= 1;
@@ -389,13 +434,13 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
                        counters, pair_cap);
     switch (S) {
 #define AW_CASE(S_) \
-    case S_: GH_CHECK((launch_build<S_, true>(ctx, (const double2 *)akerns, (const double2 *)akerns, nullptr, pairlist, A, counters, 0, 0, pair_cap, pairk))); break;
+    case S_: GH_CHECK((launch_build<S_, true>(ctx, (const double2 *)akerns, (const double2 *)akerns, nullptr, pairlist, A, counters, 0, 0, pair_cap, pairk, (int64_t)pair_cap, (int64_t)A))); break;
         AW_CASE(5) AW_CASE(7) AW_CASE(9) AW_CASE(11) AW_CASE(13) AW_CASE(15)
 #undef AW_CASE
         default: {
             int pb = pair_cap < ctx->num_cu * 8 ? pair_cap : ctx->num_cu * 8;
             hipLaunchKernelGGL(aw_pair_kernel, dim3((unsigned)(pb > 0 ? pb : 1)), dim3(256), 2 * S2 * sizeof(double2), ctx->stream,
-                               A, (int)S, (const double2 *)akerns, pairlist, counters, pair_cap, pairk);
+                               A, (int)S, (const double2 *)akerns, pairlist, counters, pair_cap, pairk, ctx->d_scalars + 31);
         }
     }
     GH_CHECK_HIP(ctx, hipGetLastError());
@@ -418,14 +463,14 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         const int which = cache ? 1 : -1;
         switch (S) {
 #define AW_CASE(S_) \
-    case S_: GH_CHECK((launch_build<S_, false>(ctx, (const double2 *)wkerns, pairk, ukey, nullptr, A, counters, which, (int32_t)m, (int32_t)batch, table))); break;
+    case S_: GH_CHECK((launch_build<S_, false>(ctx, (const double2 *)wkerns, pairk, ukey, nullptr, A, counters, which, (int32_t)m, (int32_t)batch, table, (int64_t)pair_cap, (int64_t)(W * Q * Q)))); break;
             AW_CASE(5) AW_CASE(7) AW_CASE(9) AW_CASE(11) AW_CASE(13) AW_CASE(15)
 #undef AW_CASE
             default: {
                 int gb = (int)(m < ctx->num_cu * 8 ? m : ctx->num_cu * 8);
                 hipLaunchKernelGGL(aw_build_generic_kernel, dim3((unsigned)gb), dim3(256), 2 * S2 * sizeof(double2), ctx->stream,
                                    (int)S, (const double2 *)wkerns, pairk, ukey, counters, which, (int32_t)m, (int32_t)batch,
-                                   table);
+                                   table, (int64_t)pair_cap, (int64_t)(W * Q * Q), ctx->d_scalars + 31);
             }
         }
         GH_CHECK_HIP(ctx, hipGetLastError());

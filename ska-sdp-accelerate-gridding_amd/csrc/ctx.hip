@@ -101,32 +101,57 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
         g->kb = (int32_t)(ctx->opt.rec_bits - 100) - 14 - g->ob;
 
     const size_t lds_cap = (size_t)ctx->max_lds - 1024;
-    // one plane (re or im) of the tap-reusing kernel's tile must fit below the fixed re / im distance (tile_sorted.hip)
-    constexpr size_t PLANE_CAP = 65528;
+    // one plane (re or im) of the tap-reusing kernel's tile must fit below the fixed re / im distance (tile_sorted.hip) -
+    // unless the tile is to use all of the LDS (the im plane then follows the re plane directly, at a distance the
+    // kernel adds per tap step instead of carrying it in the instruction's offset field); what the sorter's histogram
+    // needs (one counter per kernel slice of a w-group) is left free
+    // ("bigtile": 0 = auto - where items are sparse, i.e. fewer than two visibilities per kernel slice and work item with
+    // the classic tile: measured +2 % on the 8192^2 share of configuration 5, -4 % where the LDS unit binds; 1 = on;
+    // 2 = off)
+    const bool bt_ok = ctx->opt.bigtile != 2 && ctx->opt.tile == 0 && ctx->opt.tile_x == 0 && gh == gw && gh >= 5 && gh <= 32;
     auto plane_for = [&](int tx, int ty) {
         return (size_t)lds_pitch(tx + (int)gw - 1, (int)gw) * (size_t)(ty + (int)gh - 1) * 8;
     };
-    int Tx = (int)ctx->opt.tile_x, Ty = (int)ctx->opt.tile_y;
-    if (ctx->opt.tile) Tx = Ty = (int)ctx->opt.tile;  // option "tile": a square tile
-    if ((Tx == 0) != (Ty == 0)) return fail(ctx, GRIDHIP_EINVAL, "tile_x and tile_y go together");
-    if (Tx == 0) {
-        // The largest tile whose planes fit: tap reuse per work item grows with the tile's area (visibilities per
-        // distinct kernel slice = n / (tiles W Q^2)) and the halo's share shrinks.  The row pitch comes in steps of
-        // 32 cells (bank-conflict rule, lds_pitch), so the candidates are the widest tile of each pitch with the
-        // tallest height that fits: 65 x 89 for a 15 x 15 kernel, against 64 x 64 as a square power of two.
+    // The largest tile whose planes fit: tap reuse per work item grows with the tile's area (visibilities per
+    // distinct kernel slice = n / (tiles W Q^2)) and the halo's share shrinks.  The row pitch comes in steps of
+    // 32 cells (bank-conflict rule, lds_pitch), so the candidates are the widest tile of each pitch with the
+    // tallest height that fits: 65 x 89 for a 15 x 15 kernel, against 64 x 64 as a square power of two.
+    auto largest_tile = [&](bool big, int *otx, int *oty) {
+        const size_t hist_room = big ? (size_t)(((W + 7) / 8 + 2) * Q * Q) * 4 + 1024 : 24576;  // the sort's histogram
+        const size_t plane_cap = big ? lds_cap : 65528;
         size_t best = 0;
+        if (hist_room + 8192 > lds_cap) return best;
         for (int tx = 8; tx <= 128; ++tx) {
             const int pitch = lds_pitch(tx + (int)gw - 1, (int)gw);
             if (tx < 128 && lds_pitch(tx + 1 + (int)gw - 1, (int)gw) == pitch) continue;  // (not the widest of its pitch)
-            int rows = (int)(PLANE_CAP / ((size_t)pitch * 8));
-            if ((size_t)rows * pitch * 16 > lds_cap - 24576) rows = (int)((lds_cap - 24576) / ((size_t)pitch * 16));  // room for the sort's histogram
+            int rows = (int)(plane_cap / ((size_t)pitch * 8));
+            if ((size_t)rows * pitch * 16 > lds_cap - hist_room) rows = (int)((lds_cap - hist_room) / ((size_t)pitch * 16));
             int ty = rows - ((int)gh - 1);
             if (ty > 128) ty = 128;
             if (ty < 8) continue;
             if ((size_t)tx * ty > best) {
                 best = (size_t)tx * ty;
-                Tx = tx;
-                Ty = ty;
+                *otx = tx;
+                *oty = ty;
+            }
+        }
+        return best;
+    };
+    bool bigtile = false;
+    int Tx = (int)ctx->opt.tile_x, Ty = (int)ctx->opt.tile_y;
+    if (ctx->opt.tile) Tx = Ty = (int)ctx->opt.tile;  // option "tile": a square tile
+    if ((Tx == 0) != (Ty == 0)) return fail(ctx, GRIDHIP_EINVAL, "tile_x and tile_y go together");
+    if (Tx == 0) {
+        size_t best = largest_tile(false, &Tx, &Ty);
+        if (best > 0 && bt_ok) {
+            const int64_t tiles = ((H + Ty - 1) / Ty) * ((Wd + Tx - 1) / Tx);
+            const bool sparse = n >= ((int64_t)1 << 22) && n < 2 * tiles * W * Q * Q;
+            int bx = 0, by = 0;
+            if ((ctx->opt.bigtile == 1 || sparse) && largest_tile(true, &bx, &by) > best) {
+                best = (size_t)bx * by;
+                Tx = bx;
+                Ty = by;
+                bigtile = true;
             }
         }
         if (best == 0) {
@@ -148,6 +173,7 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
                     (long long)gh, (long long)gw, plane_for(Tx, Ty) * 2);
     g->Tx = Tx;
     g->Ty = Ty;
+    g->imoff = bigtile && plane_for(Tx, Ty) > 65528 ? (int32_t)plane_for(Tx, Ty) : 0;
     g->lcols = Tx + (int)gw - 1;
     g->lrows = Ty + (int)gh - 1;
     g->ldw = lds_pitch(g->lcols, (int)gw);
@@ -367,6 +393,8 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "rec_bits")) return &ctx->opt.rec_bits;
     if (!strcmp(key, "wtable")) return &ctx->opt.wtable;
     if (!strcmp(key, "reserve_cus")) return &ctx->opt.reserve_cus;
+    if (!strcmp(key, "subfoot")) return &ctx->opt.subfoot;
+    if (!strcmp(key, "bigtile")) return &ctx->opt.bigtile;
     return nullptr;
 }
 
@@ -390,6 +418,10 @@ int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value)
         GH_CHECK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_scalars + 2, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         *value = h;
+        return GRIDHIP_OK;
+    }
+    if (!strcmp(key, "last_path")) {
+        *value = ctx->last_path;
         return GRIDHIP_OK;
     }
     if (!strcmp(key, "clock_khz")) {

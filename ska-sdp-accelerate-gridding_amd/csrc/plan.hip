@@ -65,7 +65,7 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
         rc = ws_reserve(ctx, ctx->tables, tables_bytes(p->p.g));
         if (rc == GRIDHIP_OK) rc = ws_reserve(ctx, ctx->recs, (size_t)(p->p.nrec > 0 ? p->p.nrec : 1) * sizeof(RecWord));
         if (rc == GRIDHIP_OK) rc = launch_bin(ctx, p->p.g, p->p.nrec, u, v, uv_stride, wbin);
-        if (rc == GRIDHIP_OK && p->p.g.P == 1 && n > 0) {
+        if (rc == GRIDHIP_OK && p->p.g.P == 1 && !(p->p.sorted && p->p.g.gh > 16) && n > 0) {
             // how many visibilities found a bin: when all did, degrid passes skip clearing their output
             int32_t binned = 0;
             const Tables t = tables_of(ctx, p->p.g);

@@ -59,7 +59,11 @@ struct SortedItem {
 // then orders by kslice mod nkeys (equal kernels still end up next to each other unless two of them share a
 // residue) and the sorted list carries the kslice itself in place of `orig`, which gridding does not need; a run
 // is a stretch of equal kslice.
-template <int S, bool DEGRID, int ABL = 0, bool AW = false>
+// BT ("big tile"): the im plane follows the re plane at Geom.imoff bytes, a run-time distance that may exceed what a DS
+// instruction's offset field holds - the tile may then use all of the LDS (65 x 110 cells instead of 65 x 89 at
+// 15 x 15: a quarter more visibilities per slice and item, what counts where the walk waits for taps) at the price of
+// one address add per tap step.
+template <int S, bool DEGRID, int ABL = 0, bool AW = false, bool BT = false>
 __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const RecWord *__restrict__ recs,
                                                                 const int32_t *__restrict__ bin_start,
                                                                 const int32_t *__restrict__ work_start,
@@ -104,7 +108,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
     // The fixed distance lets one address register serve both atomics of a tap: the im one carries the
     // distance in its offset field (16 bits, hence the value), which takes a VALU add per tap step out of
     // the accumulate loop.
-    double *lre = lds, *lim = lds + SORTED_IM_OFF / 8;
+    const int IMO = BT ? g.imoff / 8 : SORTED_IM_OFF / 8;  // doubles from a cell's re to its im
+    double *lre = lds, *lim = lds + IMO;
     int32_t *hist = reinterpret_cast<int32_t *>(lim + plane);
     const int hist_words = (nkeys + 1 + 3) & ~3;
     SortedItem *desc = reinterpret_cast<SortedItem *>(hist + hist_words);  // [2]
@@ -277,7 +282,6 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
     // (FP > 1) this lane's place in a step that starts a row: t = (A + lrow) * S + (B + lcol) for a step whose
     // first tap is A * S + B; lcol + B may carry into the next row
     const int lrow = lane / S, lcol = lane - lrow * S;
-    const int lbase0 = lrow * g.ldw + lcol;
 
     // ---- a walker's job: its piece of the sorted list of scratch half `slot` ------------------------------
     // The piece is taken in blocks of 64 records: two coalesced loads bring a block into registers, one
@@ -306,10 +310,13 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
         auto load_value = [&](const uint2 &mo, double2 &v) {  // (mo.y = orig, brought below nvis by the sorter)
             if (!DEGRID && !STAGE_VALS) v = (ABL & 8) ? make_double2(1.0, 2.0) : load_nt(vis + mo.y);
         };
-        auto issue = [&](double2(&k)[NSTEP], int key, int len) {
+        // first step of part `part` in the slice's step list, and how many steps it has
+        auto part_step0 = [&](int part) { return FP == 1 ? 0 : part * PBASE + min(part, REM); };
+        auto part_nst = [&](int part) { return (FP == 1 || REM == 0 || part < REM) ? KST : KST - 1; };
+        auto issue = [&](double2(&k)[NSTEP], int key, int len, int part) {
             key = min(max(key, 0), (AW ? g.nslices : nkeys) - 1);  // never form an address outside the kernel table
             asm volatile("" : "+s"(key));       // (an empty run repeats a key: keep its loads loads, not copies)
-            const double2 *kp = gcf + (size_t)(first_slice + key) * S2;
+            const double2 *kp = gcf + (size_t)(first_slice + key) * S2 + 64 * part_step0(part);
             if (ABL & 4) {
 #pragma unroll
                 for (int s = 0; s < NSTEP; ++s) k[s] = make_double2((double)key, (double)(lane + s));
@@ -318,9 +325,22 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
             // the runs of length 0 that pad a block's tail keep the instruction count (and the vmcnt arithmetic)
             // but fetch one element for the whole wave
             const int lofs = len > 0 ? lane : 0, lt = len > 0 ? ttail : 0;
+            if (FP == 1) {
 #pragma unroll
-            for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lofs];
-            k[NSTEP - 1] = kp[lt];
+                for (int s = 0; s < NSTEP - 1; ++s) k[s] = kp[s * 64 + lofs];
+                k[NSTEP - 1] = kp[lt];
+            } else {
+                // always KST loads per unit (the compiler counts them for its vmcnt waits): a part of KST - 1 steps
+                // repeats its first element, one address for the whole wave, in the register it does not use
+                const bool lastp = part == FP - 1, shortp = part_nst(part) < KST;
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    int idx = s * 64 + lofs;
+                    if (s == LASTS && lastp) idx = lt;           // the list's tail step
+                    if (s == KST - 1 && shortp) idx = 0;         // no such step in this part
+                    k[s] = kp[idx];
+                }
+            }
         };
         // two blocks of the list and one block of values are in flight ahead of the block being accumulated
         uint2 moN, moNN;
@@ -346,12 +366,24 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                 for (int e = 0; e < EXTRA; ++e) kx[e] = (ABL & 4) ? make_double2(1.0, 2.0) : kp[e];
             }
             int lastKey = 0;
-            // next run of the block: its slice, first lane and length (an empty run once the block is used up)
-            auto advance = [&](int &key, int &start, int &len) {
+            int curKey = 0, curStart = 0, curLen = 0, curPart = FP - 1;  // the run whose parts are being handed out
+            // next unit of the block: a run - its slice, first lane and length - and which part of the slice's taps
+            // (an empty unit once the block is used up)
+            auto advance = [&](int &key, int &start, int &len, int &part) {
+                if (FP > 1 && curLen > 0 && curPart < FP - 1) {  // the same run, its next part
+                    ++curPart;
+                    key = curKey;
+                    start = curStart;
+                    len = curLen;
+                    part = curPart;
+                    return;
+                }
                 if (bits == 0) {
                     key = lastKey;
                     start = 0;
                     len = 0;
+                    part = FP - 1;
+                    curLen = 0;
                     return;
                 }
                 start = (int)__builtin_ctzll(bits);
@@ -359,11 +391,44 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                 len = (bits ? (int)__builtin_ctzll(bits) : bcnt) - start;
                 key = lastKey = AW ? __builtin_amdgcn_readlane((int)mo.y, start)
                                    : (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, start) >> 16);
+                part = 0;
+                if (FP > 1) {
+                    curKey = key;
+                    curStart = start;
+                    curLen = len;
+                    curPart = 0;
+                }
             };
-            auto process = [&](const double2(&k)[NSTEP], int start, int len) {
+            auto process = [&](const double2(&k)[NSTEP], int start, int len, int part) {
+                // where this unit's taps land relative to a footprint's origin.  FP = 1: the precomputed loff[].
+                // FP > 1: step s of the part starts at tap t0 = 64 * (step0 + s) = A * S + B of the list; this lane's
+                // tap is (A + lrow) * S + (B + lcol), with a carry into the next row when B + lcol >= S.
+                int lo[NSTEP];
+                const bool lastp = FP == 1 || part == FP - 1;
+                const bool shortp = FP > 1 && part_nst(part) < KST;  // (uniform) the part has KST - 1 steps
+                if (FP == 1) {
+#pragma unroll
+                    for (int s = 0; s < NSTEP; ++s) lo[s] = loff[s];
+                } else {
+                    const int st0 = part_step0(part);
+#pragma unroll
+                    for (int s = 0; s < NSTEP; ++s) {
+                        const int tl = 64 * (st0 + s);                 // (scalar) the step's first tap
+                        const int A = tl / S, B = tl - A * S;          // (scalar; S is a compile-time constant)
+                        int lr = lrow, lc = lcol;
+                        if (PAIR && s == LASTS && lastp && lane >= 32) {  // the tail step's second half: the same 32 taps again
+                            lr = (lane - 32) / S;
+                            lc = (lane - 32) - lr * S;
+                        }
+                        // (lanes of a non-PAIR tail step beyond its taps point past the footprint: they are switched
+                        // off when gridding and read cell lo[0] when degridding)
+                        const int carry = (B + lc >= S) ? g.ldw - S : 0;
+                        lo[s] = (A + lr) * g.ldw + B + lc + carry;
+                    }
+                }
                 if (!DEGRID) {
                     int i = 0;
-                    if (PAIR) {
+                    if (PAIR && lastp) {
                         for (; i + 1 < len; i += 2) {
                             const int j0 = start + i, j1 = j0 + 1;
                             const int lb0 = (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, j0) & 0xffff);
@@ -371,42 +436,42 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                             const double vx0 = readlane_f64(vB.x, j0), vy0 = readlane_f64(vB.y, j0);
                             const double vx1 = readlane_f64(vB.x, j1), vy1 = readlane_f64(vB.y, j1);
 #pragma unroll
-                            for (int s = 0; s < NSTEP - 1; ++s) {
-                                double *cell = lre + (lb0 + loff[s]);
+                            for (int s = 0; s < LASTS; ++s) {
+                                double *cell = lre + (lb0 + lo[s]);
                                 if (ABL & 1) continue;
                                 __hip_atomic_fetch_add(cell, vx0 * k[s].x - vy0 * k[s].y, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, vx0 * k[s].y + vy0 * k[s].x,
+                                __hip_atomic_fetch_add(cell + IMO, vx0 * k[s].y + vy0 * k[s].x,
                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
 #pragma unroll
-                            for (int s = 0; s < NSTEP - 1; ++s) {
-                                double *cell = lre + (lb1 + loff[s]);
+                            for (int s = 0; s < LASTS; ++s) {
+                                double *cell = lre + (lb1 + lo[s]);
                                 if (ABL & 1) continue;
                                 __hip_atomic_fetch_add(cell, vx1 * k[s].x - vy1 * k[s].y, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, vx1 * k[s].y + vy1 * k[s].x,
+                                __hip_atomic_fetch_add(cell + IMO, vx1 * k[s].y + vy1 * k[s].x,
                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                             // the shared last step: each half computes its own visibility's products (EXEC-masked
                             // branches: the empty asm keeps them branches), then all 64 lanes add
-                            const double2 kl = k[NSTEP - 1];
+                            const double2 kl = k[LASTS];
                             double re, im;
                             int a;
                             if (lane < 32) {
                                 re = vx0 * kl.x - vy0 * kl.y;
                                 im = vx0 * kl.y + vy0 * kl.x;
-                                a = lb0 + loff[NSTEP - 1];
+                                a = lb0 + lo[LASTS];
                                 asm volatile("" : "+v"(a));
                             } else {
                                 re = vx1 * kl.x - vy1 * kl.y;
                                 im = vx1 * kl.y + vy1 * kl.x;
-                                a = lb1 + loff[NSTEP - 1];
+                                a = lb1 + lo[LASTS];
                                 asm volatile("" : "+v"(a));
                             }
                             if (!(ABL & 1)) {
                                 __hip_atomic_fetch_add(lre + a, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_add(lre + a + SORTED_IM_OFF / 8, im, __ATOMIC_RELAXED,
+                                __hip_atomic_fetch_add(lre + a + IMO, im, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                         }
@@ -418,18 +483,19 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                         const double vx = readlane_f64(vB.x, j), vy = readlane_f64(vB.y, j);
 #pragma unroll
                         for (int s = 0; s < NSTEP; ++s) {
+                            if (FP > 1 && s == KST - 1 && shortp) continue;  // (uniform) this part has no such step
                             const double re = vx * k[s].x - vy * k[s].y;
                             const double im = vx * k[s].y + vy * k[s].x;
-                            double *cell = lre + (lbase + loff[s]);
+                            double *cell = lre + (lbase + lo[s]);
                             if (ABL & 1) {
                                 if (re == 1.2345e300 || im == 1.2345e300) *cell = re;  // keeps the arithmetic alive
                                 continue;
                             }
-                            // the last step's idle lanes are switched off (EXEC): an LDS atomic costs 8 cycles with
+                            // the tail step's idle lanes are switched off (EXEC): an LDS atomic costs 8 cycles with
                             // all four 16-lane groups active, 7 with three, 6 with two (tools/micro/lds_atomic.hip)
-                            if (s < NSTEP - 1 || TAIL == 64 || tail_ok) {
+                            if (TAIL == 64 || s != LASTS || !lastp || tail_ok) {
                                 __hip_atomic_fetch_add(cell, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, im, __ATOMIC_RELAXED,
+                                __hip_atomic_fetch_add(cell + IMO, im, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                         }
@@ -437,8 +503,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                 } else {
                     // four visibilities of the run at a time: their partial sums are reduced across the wave
                     // together (wave_sum4_rows), the results land in lanes 15, 31, 47 and 63
-                    // (last step's taps with zeros in the lanes that have none)
-                    const double2 kz = tail_ok ? k[NSTEP - 1] : make_double2(0.0, 0.0);
+                    // (tail step's taps with zeros in the lanes that have none)
+                    const double2 kz = tail_ok ? k[LASTS] : make_double2(0.0, 0.0);
                     for (int i = 0; i < len; i += 4) {
                         double sr[4], si[4];
                         int32_t oo[4];
@@ -454,18 +520,21 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                                 oo[q] = __builtin_amdgcn_readlane((int)mo.y, j);
                                 // all of the visibility's tile cells first (2 x NSTEP LDS reads in flight), then the
                                 // products: the reads' latency is paid once per visibility, not once per step.  The
-                                // lanes without a tap in the last step read their first cell again and multiply by a
-                                // zero tap (kz) instead of being switched off.
+                                // lanes without a tap in the tail step read a valid cell and multiply by a zero tap
+                                // (kz) instead of being switched off.
                                 double gr[NSTEP], gi[NSTEP];
 #pragma unroll
                                 for (int s = 0; s < NSTEP; ++s) {
-                                    const double *cell = lre + (lbase + loff[s]);
+                                    const bool nostep = FP > 1 && s == KST - 1 && shortp;  // (uniform)
+                                    const bool idle = TAIL != 64 && s == LASTS && lastp && !tail_ok;
+                                    const double *cell = lre + (lbase + ((idle || nostep) ? lo[0] : lo[s]));
                                     gr[s] = cell[0];
-                                    gi[s] = cell[SORTED_IM_OFF / 8];
+                                    gi[s] = cell[IMO];
                                 }
 #pragma unroll
                                 for (int s = 0; s < NSTEP; ++s) {
-                                    const double2 kk = (s == NSTEP - 1 && TAIL != 64) ? kz : k[s];
+                                    double2 kk = (TAIL != 64 && s == LASTS && lastp) ? kz : k[s];
+                                    if (FP > 1 && s == KST - 1 && shortp) kk = make_double2(0.0, 0.0);
                                     // four FMAs (written out: `sr += a*b - c*d` compiles to two multiplies, an
                                     // FMA and an add per component, and this loop is bound by vector-ALU issue)
                                     sr[q] = fma(kk.x, gr[s], sr[q]);
@@ -480,9 +549,9 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                         const int row = lane >> 4;
                         if ((lane & 15) == 15 && i + row < len) {
                             const int32_t o = row == 0 ? oo[0] : row == 1 ? oo[1] : row == 2 ? oo[2] : oo[3];
-                            if (g.P == 1)  // (written once, never read here: past the L2's taps)
+                            if (g.P == 1 && FP == 1)  // (written once, never read here: past the L2's taps)
                                 __builtin_nontemporal_store(dvec2_t{rr, ri}, reinterpret_cast<dvec2_t *>(vis + o));
-                            else {  // sub-footprints: a visibility's parts are summed (vis_out was cleared)
+                            else {  // sub-footprints, parts of the tap list: a visibility's parts are summed (vis_out was cleared)
                                 double *dst = reinterpret_cast<double *>(vis + o);
                                 unsafeAtomicAdd(dst, rr);
                                 unsafeAtomicAdd(dst + 1, ri);
@@ -492,32 +561,32 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                 }
             };
 
-            // NSETS tap sets used in strict rotation: while run r is accumulated from one set, the taps of runs
-            // r+1 .. r+NSETS-1 are in flight into the others.  Three sets, two runs ahead (a fourth, which the gridding
+            // NSETS tap sets used in strict rotation: while unit r is accumulated from one set, the taps of units
+            // r+1 .. r+NSETS-1 are in flight into the others.  Three sets, two units ahead (a fourth, which the gridding
             // instantiations have the registers for, measured no faster at 4096^2 and 1 % slower at 8192^2: what the
             // walkers wait for there is the L2's bandwidth, not its latency).  The only loop exit sits after a full
             // trip over the sets and every set is "used" after it, so LLVM cannot sink a prefetch past the exit test;
-            // runs of length 0 pad the tail.
+            // units of length 0 pad the tail.
             constexpr int NSETS = 3;
             double2 kS[NSETS][NSTEP];
-            int keyS[NSETS], startS[NSETS], lenS[NSETS];
+            int keyS[NSETS], startS[NSETS], lenS[NSETS], partS[NSETS];
 #pragma unroll
             for (int r = 0; r < NSETS - 1; ++r) {
-                advance(keyS[r], startS[r], lenS[r]);
-                issue(kS[r], keyS[r], lenS[r]);
+                advance(keyS[r], startS[r], lenS[r], partS[r]);
+                issue(kS[r], keyS[r], lenS[r], partS[r]);
             }
             int done = 0;
             for (;;) {
 #pragma unroll
                 for (int r = 0; r < NSETS; ++r) {
                     const int nx = (r + NSETS - 1) % NSETS;  // (compile time after unrolling)
-                    advance(keyS[nx], startS[nx], lenS[nx]);
-                    issue(kS[nx], keyS[nx], lenS[nx]);
+                    advance(keyS[nx], startS[nx], lenS[nx], partS[nx]);
+                    issue(kS[nx], keyS[nx], lenS[nx], partS[nx]);
                     asm volatile("" ::: "memory");  // compiler fence: the prefetch may not sink below this point
                     __builtin_amdgcn_sched_barrier(0);
-                    process(kS[r], startS[r], lenS[r]);
+                    process(kS[r], startS[r], lenS[r], partS[r]);
                     __builtin_amdgcn_sched_barrier(0);
-                    done += lenS[r];
+                    if (FP == 1 || partS[r] == FP - 1) done += lenS[r];  // (a run is done with its last part)
                 }
                 if (done >= bcnt) break;
             }
@@ -535,7 +604,7 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                     double *cell = lre + (lb + (t / S) * g.ldw + (t % S));
                     __hip_atomic_fetch_add(cell, vB.x * kx[e].x - vB.y * kx[e].y, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(cell + SORTED_IM_OFF / 8, vB.x * kx[e].y + vB.y * kx[e].x, __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(cell + IMO, vB.x * kx[e].y + vB.y * kx[e].x, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -633,15 +702,15 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
 // histogram.  On success returns the LDS bytes and the largest work item (records) it takes.
 bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, int *batch, size_t *lds_bytes)
 {
-    // square supports with a compile-time instantiation below
-    if (g.gh != g.gw || g.gh < 5 || g.gh > 16) return false;
+    // square supports with a compile-time instantiation below (the aw form: up to 16)
+    if (g.gh != g.gw || g.gh < 5 || g.gh > (g.per_vis ? 16 : 32)) return false;
     const int planes = (g.W + g.ngroups - 1) / g.ngroups + 1;  // groups differ by at most one plane
     // (aw gridders: the sort is by kslice mod 4096)
     const int64_t keys = g.per_vis ? 4096 : (int64_t)planes * g.Q * g.Q * g.P;
     if (keys >= 65536) return false;
     const size_t plane = (size_t)g.lrows * g.ldw * 8;
-    if (plane > (size_t)SORTED_IM_OFF) return false;
-    const size_t tile = (size_t)SORTED_IM_OFF + plane;  // re plane, gap, im plane
+    if (plane > (size_t)(g.imoff > 0 ? g.imoff : SORTED_IM_OFF)) return false;
+    const size_t tile = (size_t)(g.imoff > 0 ? g.imoff : SORTED_IM_OFF) + plane;  // re plane, (gap,) im plane
     const size_t hist = (size_t)((keys + 1 + 3) & ~3) * 4;
     if (tile + hist + 128 > (size_t)ctx->max_lds) return false;
     (void)block;
@@ -660,6 +729,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     const RecWord *recs = (const RecWord *)ctx->recs.ptr;
     if (g.chunk > batch) return fail(ctx, GRIDHIP_EINVAL, "sorted kernel: chunk %d exceeds its work-item capacity %d", g.chunk, batch);
     if (g.per_vis && degrid) return fail(ctx, GRIDHIP_EUNSUPPORTED, "no degrid form of the aw tile kernel");
+    if (g.per_vis && g.imoff > 0) return fail(ctx, GRIDHIP_EUNSUPPORTED, "no big-tile form of the aw tile kernel");
     // persistent work-groups: as many as can be resident (LDS-limited), pulling items from per-group queues
     int per_cu = (int)((size_t)ctx->max_lds / lds_bytes);
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
@@ -679,12 +749,19 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     double2 *svals = (double2 *)ctx->sorted.ptr;  // (not dereferenced when nothing is staged)
     uint2 *smo = (uint2 *)(svals + nvals);
     launch_clear(ctx, t.scalars + 4, 16, (g.dbg & 16) ? t.scalars + 32 : nullptr, (g.dbg & 16) ? 64 : 0);  // the w-groups' queues
-#define GH_LAUNCH(S_, D_)                                                                                        \
+#define GH_LAUNCH_(S_, D_, B_)                                                                                   \
     do {                                                                                                         \
-        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_>));                                               \
-        hipLaunchKernelGGL((tile_grid_sorted_kernel<S_, D_>), gr, bl, lds_bytes, ctx->stream, g, recs,           \
+        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<S_, D_, 0, false, B_>));                                 \
+        hipLaunchKernelGGL((tile_grid_sorted_kernel<S_, D_, 0, false, B_>), gr, bl, lds_bytes, ctx->stream, g, recs, \
                            t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
                            t.scalars, svals, smo);                                                               \
+    } while (0)
+#define GH_LAUNCH(S_, D_)                \
+    do {                                 \
+        if (g.imoff > 0)                 \
+            GH_LAUNCH_(S_, D_, true);    \
+        else                             \
+            GH_LAUNCH_(S_, D_, false);   \
     } while (0)
 #define GH_LAUNCH_AW(S_)                                                                                         \
     do {                                                                                                         \
@@ -702,6 +779,14 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
         else                    \
             GH_LAUNCH(S_, false); \
         break;
+#define GH_BIG(S_)                                                                  \
+    case S_:                                                                        \
+        if (g.per_vis) return fail(ctx, GRIDHIP_EUNSUPPORTED, "aw tile kernel: support %d", g.gh); \
+        if (degrid)                                                                 \
+            GH_LAUNCH(S_, true);                                                    \
+        else                                                                        \
+            GH_LAUNCH(S_, false);                                                   \
+        break;
 #define GH_ABL(A_)                                                                                               \
     if (g.gh == 15 && !degrid && g.dbg == A_) {                                                                  \
         GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<15, false, A_>));                                        \
@@ -718,10 +803,14 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     switch (g.gh) {
         GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)
         GH_CASE(14) GH_CASE(15) GH_CASE(16)
+        GH_BIG(17) GH_BIG(18) GH_BIG(19) GH_BIG(20) GH_BIG(21) GH_BIG(22) GH_BIG(23) GH_BIG(24) GH_BIG(25) GH_BIG(26)
+        GH_BIG(27) GH_BIG(28) GH_BIG(29) GH_BIG(30) GH_BIG(31) GH_BIG(32)
         default: return fail(ctx, GRIDHIP_EUNSUPPORTED, "no sorted instantiation for support %d", g.gh);
     }
 #undef GH_CASE
+#undef GH_BIG
 #undef GH_LAUNCH
+#undef GH_LAUNCH_
 #undef GH_LAUNCH_AW
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;

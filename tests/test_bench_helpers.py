@@ -20,6 +20,11 @@ def test_algorithmic_bytes_per_visibility():
     (5, 12),        # 25 taps: two groups -> 6 cycles
     (11, 32),       # 121 taps: 64 + 57
     (13, 46),       # 169 taps: 2 x 64 + 41 (three groups: 7 cycles)
+    (17, 72.25),    # 289 taps: four full steps, a shared 32-tap step, 1 tap per block (parts of 3 + 2 steps)
+    (21, 112),      # 441 taps: 6 x 64 + 57
+    (25, 160),      # 625 taps: 9 x 64 + 49
+    (31, 240.25),   # 961 taps: 15 x 64, the last tap once per block of 64 records
+    (32, 256),
 ])
 def test_lds_atomic_cycles_per_visibility(S, cycles):
     assert bench.lds_atomic_cycles_per_vis(S) == cycles

@@ -427,9 +427,12 @@ def test_degrid2_writes_zero_for_dropped_visibilities(ctx, oracle, prepass):
     (128, 128, 1, 1, 1, 1, 30000, {}),
 ])
 @pytest.mark.parametrize("dist", ["uniform", "core"])
-def test_subfootprints_large_and_nonsquare_supports(ctx, oracle, N, M, W, Q, gh, gw, n, opts, dist):
-    """Supports above 16 and non-square kernels through the tap-reusing kernel: the kernel is cut into zero-padded
-    square parts and every visibility becomes one record per part (own footprint origin, tile and slice).
+@pytest.mark.parametrize("subfoot", [0, 1])
+def test_subfootprints_large_and_nonsquare_supports(ctx, oracle, N, M, W, Q, gh, gw, n, opts, dist, subfoot):
+    """Supports above 16 and non-square kernels through the tap-reusing kernel.  Square supports 17..32 (subfoot = 0):
+    one record per visibility, the kernel takes a slice's taps in parts of at most four steps.  Everything else, and
+    all of them under option "subfoot" = 1 (round 2's cut, parts of side <= 16): the kernel table is cut into
+    zero-padded square parts and every visibility becomes one record per part (own footprint origin, tile and slice).
     Grid, degrid (a visibility's parts are summed), a plan, and coordinates spilling over the grid edges."""
     import torch
     gcf, u, v, wb, vis = case(N + gh * 3 + gw, N, M, W, Q, gh, gw, n, spread=0.58, dist=dist)
@@ -441,6 +444,7 @@ def test_subfootprints_large_and_nonsquare_supports(ctx, oracle, N, M, W, Q, gh,
     t = lambda a: torch.from_numpy(a).to(dev)
     try:
         ctx.set_option("sort", 1)
+        ctx.set_option("subfoot", subfoot)
         for k, val in opts.items():
             ctx.set_option(k, val)
         got = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
@@ -454,11 +458,46 @@ def test_subfootprints_large_and_nonsquare_supports(ctx, oracle, N, M, W, Q, gh,
         ctx.set_option("prepass", 2)   # the two-level scatter with pre-records, one record per part
         got2 = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
     finally:
-        for k in ("sort", "tile", "block", "wgroups", "prepass"):
+        for k in ("sort", "tile", "block", "wgroups", "prepass", "subfoot"):
             ctx.set_option(k, 0)
     assert e1 == 0 and e2 == 0
     assert rel(got, ref) < TOL and rel(got2, ref) < TOL and rel(pg, ref) < TOL
     assert rel(d, dref) < TOL and rel(pd, dref) < TOL
+
+
+@pytest.mark.parametrize("S", list(range(17, 33)))
+def test_every_support_17_to_32_in_parts_of_the_tap_list(ctx, oracle, S):
+    """Each square support the tap-reusing kernel is instantiated for above 16 x 16 (a slice's steps in 2..4 parts,
+    one record per visibility): grid, degrid and a plan against the oracle, dense enough that runs of equal slice hold
+    several visibilities (the pair path of a 32-tap last step, the per-block extra taps of 17 x 17 and 31 x 31), with
+    footprints spilling over every grid edge, on a non-square grid."""
+    import torch
+    N, M, W, Q, n = 288, 352, 3, 2, 70000
+    gcf, u, v, wb, vis = case(1000 + S, N, M, W, Q, S, S, n, spread=0.6)
+    ref = oracle.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
+    rng = np.random.default_rng(S)
+    G = rng.normal(size=(N, M)) + 1j * rng.normal(size=(N, M))
+    dref = oracle.degrid2(gcf, G, u, v, wb)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    try:
+        ctx.set_option("sort", 1)
+        got = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
+        d = ctx.degrid2(gcf, G, (u, v, None), wb)
+        errors = ctx.get_option("errors")
+        plan = ctx.plan((N, M), gcf.shape, (t(u), t(v), None), t(wb))
+        pd = plan.degrid(t(gcf), t(G)).cpu().numpy()
+        pd2 = plan.degrid(t(gcf), t(G), out=torch.full((n,), 7.0 + 1j, dtype=torch.complex128, device=dev)).cpu().numpy()
+        plan.close()
+        ctx.set_option("wgroups", 1)
+        ctx.set_option("tile", 24)
+        got_small = ctx.convgrid2(gcf, np.zeros((N, M), dtype=np.complex128), (u, v, None), wb, vis)
+    finally:
+        for k in ("sort", "wgroups", "tile"):
+            ctx.set_option(k, 0)
+    assert errors == 0
+    assert rel(got, ref) < TOL and rel(got_small, ref) < TOL
+    assert rel(d, dref) < TOL and rel(pd, dref) < TOL and rel(pd2, dref) < TOL
 
 
 @pytest.mark.parametrize("N,W,Q,S,n,opts", [(512, 32, 8, 15, 150000, {}), (300, 16, 4, 7, 80000, {}),
