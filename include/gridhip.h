@@ -119,7 +119,7 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  * problems, and the sizes listed under "Limits" below: 2 - 3 x slower per visibility at scale), 4 = direct
  * global-atomic scatter; "errors" = internal consistency failures counted by the last tile-kernel
  * launch (expected 0); "clock_khz" = shader clock held during the last tap-reusing tile kernel (in-kernel
- * s_memtime / s_memrealtime stamps); "prof0".."prof31" = cycle counters of a dbg=16 launch of the tuning build (tools/phase_profile.py).
+ * s_memtime / s_memrealtime stamps), "aw_clock_khz" = the same for the last launch of the aw gridders' kernel builder; "prof0".."prof31" = cycle counters of a dbg=16 launch of the tuning build (tools/phase_profile.py).
  */
 int gridhip_set_option(gridhip_ctx *ctx, const char *key, int64_t value);
 int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value);

@@ -220,6 +220,14 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
     static_assert(S <= 16, "one 16-lane row per kernel");
     extern __shared__ double2 sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // shader clock held during this launch (read-only option "aw_clock_khz"): cycle counter and 100 MHz real-time counter
+    // stamped by the first work-group when it starts and when it is done; errors points at scalars[31], the stamps are
+    // scalars[96..103]
+    long long *stamp = reinterpret_cast<long long *>(errors + (96 - 31));
+    if (!PAIR && blockIdx.x == 0 && threadIdx.x == 0) {
+        stamp[0] = (long long)__builtin_amdgcn_s_memtime();
+        stamp[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
     const int q = lane >> 4, x = lane & 15;
     double2 *abuf = sm + (size_t)(wave * 4 + q) * (S2 + BSZ);  // this kernel's pair kernel ...
     double2 *bbuf = abuf + S2;                                  // ... and padded w-kernel slice
@@ -301,6 +309,10 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
 #pragma unroll
             for (int y = 0; y < S; ++y) out[y] = make_double2(acc[y].x, PAIR ? acc[y].y : -acc[y].y);
         }
+    }
+    if (!PAIR && blockIdx.x == 0 && threadIdx.x == 0) {
+        stamp[2] = (long long)__builtin_amdgcn_s_memtime();
+        stamp[3] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -424,12 +424,13 @@ int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value)
         *value = ctx->last_path;
         return GRIDHIP_OK;
     }
-    if (!strcmp(key, "clock_khz")) {
-        // read-only: shader clock held during the last sorted tile kernel, from the s_memtime / s_memrealtime
-        // (100 MHz) stamps its first work-group takes when it starts and when its queues are empty
+    if (!strcmp(key, "clock_khz") || !strcmp(key, "aw_clock_khz")) {
+        // read-only: shader clock held during the last sorted tile kernel (aw_clock_khz: the last aw kernel-build
+        // launch), from the s_memtime / s_memrealtime (100 MHz) stamps its first work-group takes when it starts
+        // and when its queues are empty
         GH_CHECK_HIP(ctx, hipSetDevice(ctx->device));
         int64_t h[4] = {0, 0, 0, 0};
-        GH_CHECK_HIP(ctx, hipMemcpyAsync(h, ctx->d_scalars + 20, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        GH_CHECK_HIP(ctx, hipMemcpyAsync(h, ctx->d_scalars + (key[0] == 'a' ? 96 : 20), sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const int64_t cyc = h[2] - h[0], ticks = h[3] - h[1];
         *value = ticks > 0 && cyc > 0 ? (int64_t)((double)cyc / (double)ticks * 1e5) : 0;
