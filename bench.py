@@ -664,7 +664,8 @@ def main():
                     "what": "fp64 flops of the kernel builds (8 per complex product, 28 561 products per 15x15 kernel) over the "
                             "device time of the build phase; peak = CUs x 128 flop/clk x the nominal clock",
                     "flops_per_launch": flops, "kernel_ms_avg": build_ms, "build_ms": stats(pre_ms),
-                    "grid_ms": stats(ker_ms), "aw_cache": args.aw_cache, "aw": info}
+                    "grid_ms": stats(ker_ms), "aw_cache": args.aw_cache, "aw": info,
+                    "clock_GHz_held_by_the_builder": ctx.get_option("aw_clock_khz") / 1e6, "clock_GHz_nominal": nominal_ghz}
             metric = "Mvis/s gridded (aw-proj, 4096^2 grid)"
             what = f"aw-projection grid (convgrid4): {n_rank} vis/GPU, {N}^2 grid, {W} w-planes, {AW_ANTENNAS} antennas, {S}x{S} support, Q={Q}"
         else:

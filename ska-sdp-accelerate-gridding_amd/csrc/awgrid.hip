@@ -208,7 +208,9 @@ __global__ void aw_build_generic_kernel(int S, const double2 *__restrict__ wkern
 // zeros in front of row 0), so a column index of -c .. S-1+c needs no bounds logic.
 // PAIR: the same machine builds the antenna-pair products: entry s = convolve2d(akerns[p], akerns[q]) for
 // pairlist[s] = p * A + q (wkerns = pairk = akerns, not conjugated).
-template <int S, bool PAIR>
+// ABL (tuning builds, option "dbg"): 1 = the operands are read from LDS once per group instead of once per column j
+// (wrong results: what the loop costs without its LDS reads), 2 = no stores of the results
+template <int S, bool PAIR, int ABL = 0>
 __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
                                                        const unsigned long long *__restrict__ ukey,
                                                        const int32_t *__restrict__ pairlist, int64_t A,
@@ -284,13 +286,22 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
 #pragma unroll
         for (int y = 0; y < S; ++y) acc[y] = make_double2(0.0, 0.0);
         const int xc = x < S ? x : S - 1;  // (the 16th lane of a row repeats the 15th: its results are not stored)
+        double2 acol[S], bcol[S];
+        if (ABL & 1) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) acol[i] = abuf[i * S];
+#pragma unroll
+            for (int r = 0; r < S; ++r) bcol[r] = bbuf[C + xc + C + r * PB];
+        }
         for (int j = 0; j < S; ++j) {
-            double2 acol[S], bcol[S];
             const double2 *bp = bbuf + C + (xc + C - j);  // b[r][xc + C - j] = bp[r * PB]
+            if (!(ABL & 1)) {
 #pragma unroll
-            for (int i = 0; i < S; ++i) acol[i] = abuf[i * S + j];
+                for (int i = 0; i < S; ++i) acol[i] = abuf[i * S + j];
 #pragma unroll
-            for (int r = 0; r < S; ++r) bcol[r] = bp[r * PB];
+                for (int r = 0; r < S; ++r) bcol[r] = bp[r * PB];
+            } else
+                asm volatile("" : "+v"(acol[0].x), "+v"(bcol[0].x));  // (keeps the loop a loop)
 #pragma unroll
             for (int i = 0; i < S; ++i) {
 #pragma unroll
@@ -304,7 +315,7 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
                 }
             }
         }
-        if (have && x < S) {  // out[x * S + y]: the result comes out transposed, and is conjugated
+        if (have && x < S && !((ABL & 2) && acc[0].x != 1.2345e300)) {  // out[x * S + y]: the result comes out transposed, and is conjugated
             double2 *out = table + (size_t)id * S2 + (size_t)x * S;
 #pragma unroll
             for (int y = 0; y < S; ++y) out[y] = make_double2(acc[y].x, PAIR ? acc[y].y : -acc[y].y);
@@ -358,6 +369,19 @@ int launch_build(gridhip_ctx *ctx, const double2 *wk, const double2 *pairk, cons
 {
     constexpr int C = S / 2, PB = S + C, BSZ = C + S * PB;
     const size_t lds = (size_t)16 * (S * S + BSZ) * sizeof(double2);
+#ifdef GRIDHIP_TUNING
+    if (S == 15 && !PAIR && ctx->opt.dbg >= 1 && ctx->opt.dbg <= 3) {  // ablations of the key builder (wrong results)
+#define AW_ABL1(A_)                                                                                                         \
+    if (ctx->opt.dbg == A_) {                                                                                               \
+        GH_CHECK(raise_lds(ctx, aw_build_kernel<15, false, A_>));                                                           \
+        hipLaunchKernelGGL((aw_build_kernel<15, false, A_>), dim3(ctx->num_cu), dim3(256), lds, ctx->stream, wk, pairk, ukey, \
+                           pairlist, A, counters, which, fixed, cap, table, npair_cap, nslice, ctx->d_scalars + 31);       \
+    }
+        AW_ABL1(1) AW_ABL1(2) AW_ABL1(3)
+#undef AW_ABL1
+        return GRIDHIP_OK;
+    }
+#endif
     GH_CHECK(raise_lds(ctx, aw_build_kernel<S, PAIR>));
     // one work-group (four waves, one per SIMD) per CU; the loop strides over the entries
     hipLaunchKernelGGL((aw_build_kernel<S, PAIR>), dim3(ctx->num_cu), dim3(256), lds, ctx->stream, wk, pairk, ukey, pairlist, A,

@@ -27,8 +27,10 @@ def test_smalltest_aw_fixture(ctx, golden):
 
 
 @pytest.mark.parametrize("N,W,Q,S,A,n", [(64, 3, 2, 15, 6, 300), (96, 2, 4, 7, 12, 500), (80, 4, 1, 9, 3, 200),
-                                         (72, 2, 2, 16, 4, 150), (90, 2, 2, 19, 3, 60), (64, 2, 2, 4, 5, 300)])
+                                         (72, 2, 2, 16, 4, 150), (90, 2, 2, 19, 3, 60), (64, 2, 2, 4, 5, 300),
+                                         (64, 2, 2, 5, 4, 300), (72, 3, 2, 11, 5, 250), (80, 2, 3, 13, 4, 250)])
 def test_awgrid_matches_oracle(ctx, oracle, N, W, Q, S, A, n):
+    """every compile-time support of the kernel builder (5 .. 15) and the generic builder (4, 16, 19)"""
     rng = np.random.default_rng(N + S)
     wk = rng.normal(size=(W, Q, Q, S, S)) + 1j * rng.normal(size=(W, Q, Q, S, S))
     ak = rng.normal(size=(A, S, S)) + 1j * rng.normal(size=(A, S, S))
