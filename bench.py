@@ -74,6 +74,9 @@ def parse_args(argv=None):
                     help="compute units the persistent tile kernel leaves free for the collective's kernel "
                          "(-1 = auto: 32 when N > 1 - one per shader engine of every XCD, what lets a many-work-group kernel start beside it, profiles/r03_reserve_cus.txt - else 0)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EEDC0DE)
+    ap.add_argument("--grids", type=int, default=0,
+                    help="N = 1: how many zeroed grids the steps rotate over (0 = one per step, at most 16; 1 = every step "
+                         "accumulates into the same grid, as the round-2 bench did)")
     ap.add_argument("--opt", action="append", default=[], help="gridhip option key=value (tile, block, chunk, wgroups, variant, sort)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per tile-kernel launch from a separate rocprofv3 --pmc pass "
@@ -508,7 +511,7 @@ def main():
     # the timed region") - a ring of zeroed grids, one per step (more steps than grids: the ring wraps and a grid
     # receives several whole passes, which the check below accounts for).
     # N > 1: two buffers used alternately; a step clears its buffer (each step reduces its own partial grids).
-    nbuf = 2 if dist is not None else max(1, min(args.steps + args.warmup, 16))
+    nbuf = 2 if dist is not None else max(1, min(args.grids or (args.steps + args.warmup), 16))
     bufs = [torch.zeros((N, N), dtype=torch.complex128, device=device) for _ in range(nbuf)]
     passes = [0] * nbuf
     G = bufs[0]

@@ -384,8 +384,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                     key = lastKey;
                     start = 0;
                     len = 0;
-                    part = FP - 1;
-                    curLen = 0;
+                    if (FP > 1) part = FP - 1;  // (FP = 1: `part` stays the 0 it was initialised with - written here, the
+                    curLen = 0;                 // compiler kept the array of parts in scratch memory: 3.6 GB of stores per launch)
                     return;
                 }
                 start = (int)__builtin_ctzll(bits);
@@ -393,8 +393,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
                 len = (bits ? (int)__builtin_ctzll(bits) : bcnt) - start;
                 key = lastKey = AW ? __builtin_amdgcn_readlane((int)mo.y, start)
                                    : (int)((uint32_t)__builtin_amdgcn_readlane((int)mo.x, start) >> 16);
-                part = 0;
                 if (FP > 1) {
+                    part = 0;
                     curKey = key;
                     curStart = start;
                     curLen = len;
@@ -571,7 +571,8 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
             // units of length 0 pad the tail.
             constexpr int NSETS = 3;
             double2 kS[NSETS][NSTEP];
-            int keyS[NSETS], startS[NSETS], lenS[NSETS], partS[NSETS];
+            int keyS[NSETS], startS[NSETS], lenS[NSETS], partS[NSETS] = {0, 0, 0};
+            static_assert(NSETS == 3, "initialiser of partS");
 #pragma unroll
             for (int r = 0; r < NSETS - 1; ++r) {
                 advance(keyS[r], startS[r], lenS[r], partS[r]);
@@ -790,7 +791,7 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
             GH_LAUNCH(S_, false);                                                   \
         break;
 #define GH_ABL(A_)                                                                                               \
-    if (g.gh == 15 && !degrid && g.dbg == A_) {                                                                  \
+    if (g.gh == 15 && !degrid && g.imoff == 0 && g.dbg == A_) {                                                  \
         GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<15, false, A_>));                                        \
         hipLaunchKernelGGL((tile_grid_sorted_kernel<15, false, A_>), gr, bl, lds_bytes, ctx->stream, g, recs,    \
                            t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \

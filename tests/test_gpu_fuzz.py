@@ -13,13 +13,17 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def make_case(seed):
+def make_case(seed, large=False):
     rng = np.random.default_rng(1000 + seed)
     H = int(rng.integers(17, 400))
     Wd = H if rng.random() < 0.5 else int(rng.integers(17, 400))
-    square = rng.random() < 0.7
-    gh = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 11, 13, 15, 17, 21, 25, 31, 33]))
-    gw = gh if square else int(rng.choice([1, 3, 4, 5, 7, 9, 12, 15, 19, 28]))
+    square = rng.random() < (0.85 if large else 0.7)
+    if large:  # supports 17 .. 32: the tap-reusing kernel takes a slice's taps in parts; others through sub-footprints
+        gh = int(rng.integers(17, 33))
+        gw = gh if square else int(rng.choice([18, 23, 27, 36, 40]))
+    else:
+        gh = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 11, 13, 15, 17, 21, 25, 31, 33]))
+        gw = gh if square else int(rng.choice([1, 3, 4, 5, 7, 9, 12, 15, 19, 28]))
     Q = int(rng.choice([1, 2, 3, 4, 8]))
     W = int(rng.choice([1, 2, 5, 8, 13, 32]))
     n = int(rng.choice([1, 7, 300, 5000, 40000, 120000]))
@@ -43,13 +47,22 @@ def make_case(seed):
         opts["chunk"] = int(rng.choice([64, 100, 1000, 5000]))
     opts["sort"] = int(rng.choice([0, 1, 2]))
     opts["prepass"] = int(rng.choice([0, 1, 2, 4, 5, 6]))  # one- or two-level scatter in the binning pre-pass (and its variants)
+    if large:
+        opts["sort"] = int(rng.choice([0, 1, 1]))
+        opts["bigtile"] = int(rng.choice([0, 1, 2]))
+        opts["subfoot"] = int(rng.choice([0, 0, 1]))
+        opts["reserve_cus"] = int(rng.choice([0, 8, 32, 200]))
+        if "tile" in opts and rng.random() < 0.5:
+            del opts["tile"]  # (bigtile only applies to automatically chosen tiles)
     return (H, Wd, gcf, u, v, wb, vis, opts)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", list(range(40)) + [f"L{i}" for i in range(24)])
 def test_fuzz_convgrid2_and_degrid2(ctx, oracle, seed):
-    H, Wd, gcf, u, v, wb, vis, opts = make_case(seed)
-    keys = ("tile", "block", "wgroups", "chunk", "sort", "prepass")
+    large = isinstance(seed, str)
+    seed = 500 + int(seed[1:]) if large else seed
+    H, Wd, gcf, u, v, wb, vis, opts = make_case(seed, large)
+    keys = ("tile", "block", "wgroups", "chunk", "sort", "prepass", "bigtile", "subfoot", "reserve_cus")
     G0 = np.zeros((H, Wd), dtype=np.complex128)
     ref = oracle.convgrid2(gcf, G0.copy(), u, v, wb, vis)
     rng = np.random.default_rng(seed)

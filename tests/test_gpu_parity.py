@@ -814,3 +814,52 @@ def test_reserved_cus_do_not_change_the_grid(ctx, oracle):
     finally:
         ctx.set_option("reserve_cus", 0)
         ctx.set_option("sort", 0)
+
+
+@pytest.mark.parametrize("S", [15, 21, 9])
+def test_bigtile_matches_oracle(ctx, oracle, S):
+    """Option "bigtile": the tap-reusing kernel's tile uses all of the LDS, its im plane at a run-time distance from
+    the re plane (the BT instantiations).  Only grids with room for 1 024 such tiles get them, hence the grid size;
+    grid and degrid against the oracle, and the geometry really is the big one (fewer, larger bins: the pre-pass's
+    record count per bin shows in nothing the ABI exposes, so the check is that both settings agree with the oracle
+    while their timings differ is left to tools/sweep.py)."""
+    N, W, Q, n = 3200, 16, 4, 1_500_000
+    gcf, u, v, wb, vis = case(4000 + S, N, N, W, Q, S, S, n, spread=0.52)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
+    rng = np.random.default_rng(S)
+    G = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    dref = oracle.degrid2(gcf, G, u, v, wb)
+    try:
+        for bt in (1, 2):
+            ctx.set_option("bigtile", bt)
+            ctx.set_option("sort", 1)
+            got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+            assert ctx.get_option("last_path") == 1 and ctx.get_option("errors") == 0
+            assert rel(got, ref) < TOL, bt
+            d = ctx.degrid2(gcf, G, (u, v, None), wb)
+            assert rel(d, dref) < TOL, bt
+    finally:
+        ctx.set_option("bigtile", 0)
+        ctx.set_option("sort", 0)
+
+
+def test_last_path_reports_which_gridder_ran(ctx):
+    """read-only option "last_path": 1 = tap-reusing kernel, 2 = through sub-footprints, 3 = general tile kernel,
+    4 = direct atomics - a call that falls off the fast path says so (include/gridhip.h, "Limits")"""
+    def run(S, gw, n, **opts):
+        gcf, u, v, wb, vis = case(1, 256, 256, 2, 2, S, gw, n)
+        try:
+            for k, val in opts.items():
+                ctx.set_option(k, val)
+            ctx.convgrid2(gcf, np.zeros((256, 256), dtype=np.complex128), (u, v, None), wb, vis)
+            return ctx.get_option("last_path")
+        finally:
+            for k in opts:
+                ctx.set_option(k, 0)
+    assert run(15, 15, 60000, sort=1) == 1
+    assert run(25, 25, 60000, sort=1) == 1          # parts of the tap list: still one record per visibility
+    assert run(25, 25, 60000, sort=1, subfoot=1) == 2
+    assert run(9, 5, 60000, sort=1) == 2             # non-square: sub-footprints
+    assert run(15, 15, 500) == 3                     # too few visibilities per work item for the sort to pay
+    assert run(15, 15, 60000, sort=2) == 3
+    assert run(15, 15, 60000, variant=1) == 4
