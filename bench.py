@@ -71,8 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--reduce-rows", default="auto", choices=["auto", "all"],
                     help="auto: the stream is mirrored (v >= 0), so only the rows it can touch are reduced (half the bytes)")
     ap.add_argument("--reserve-cus", type=int, default=-1,
-                    help="compute units the persistent tile kernel leaves free for the collective's kernel "
-                         "(-1 = auto: 32 when N > 1 - one per shader engine of every XCD, what lets a many-work-group kernel start beside it, profiles/r03_reserve_cus.txt - else 0)")
+                    help="compute units the persistent tile kernel leaves free for the collective's kernel (-1 = auto: N > 1 "
+                         "measures the collective alone in an untimed pass and reserves 32 - one per shader engine of every "
+                         "XCD, profiles/r03_reserve_cus.txt - when it takes more than the 10 %% of the gridding step the "
+                         "reservation costs; 0 otherwise)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EEDC0DE)
     ap.add_argument("--grids", type=int, default=0,
                     help="N = 1: how many zeroed grids the steps rotate over (0 = one per step, at most 16; 1 = every step "
@@ -497,7 +499,10 @@ def main():
         ctx.set_option(k, int(val))
     if aw:
         ctx.set_option("aw_cache", args.aw_cache)
-    reserve = args.reserve_cus if args.reserve_cus >= 0 else (32 if world > 1 else 0)
+    # CUs the persistent tile kernel leaves free for the collective's kernel: given, or (N > 1, -1) decided in the
+    # warm-up below from what the collective and the reservation each cost
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else 0
+    reserve_why = "given" if args.reserve_cus >= 0 else "auto: one GPU"
     if reserve:
         ctx.set_option("reserve_cus", reserve)
 
@@ -544,6 +549,33 @@ def main():
             red.end(i)
 
     ctx.enable_timing(True)
+    if dist is not None and args.reserve_cus < 0:
+        # Untimed tuning pass: reserving 32 CUs (one per shader engine of every XCD: what lets a many-work-group kernel
+        # start beside the tile kernel, profiles/r03_reserve_cus.txt) costs the gridding ~10 %; it pays when the
+        # collective, which otherwise runs after the tile kernel, takes longer than that.  Both are measured here, the
+        # slowest rank decides for all.
+        step()
+        red.finish()
+        torch.cuda.synchronize()
+        t_grid = sum(ctx.timing(0)[1:3])
+        dist.barrier()
+        part0 = bufs[0] if rows is None else bufs[0][rows[0]:rows[1]]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.all_reduce(torch.view_as_real(part0))
+        e0.record()
+        for _ in range(3):
+            dist.all_reduce(torch.view_as_real(part0))
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([t_grid, e0.elapsed_time(e1) / 3], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_grid, t_coll = float(t[0].item()), float(t[1].item())
+        reserve = 32 if t_coll > 0.10 * t_grid else 0
+        reserve_why = (f"auto: collective alone {t_coll:.2f} ms against 10 % of the {t_grid:.2f} ms gridding step "
+                       f"(what reserving 32 CUs costs)")
+        ctx.set_option("reserve_cus", reserve)
+        counter[0] = 0
+        passes[:] = [0] * nbuf
     for _ in range(args.warmup):
         step()
     if red:
@@ -636,7 +668,7 @@ def main():
         ar_ms = e0.elapsed_time(e1) / 5
         nbytes = int(part.numel() * 16)
         multi = {"rccl_ranks": dist.get_world_size(), "collective": args.collective, "scaling": args.scaling,
-                 "reduced_rows": list(rows) if rows else [0, N], "reserve_cus": reserve,
+                 "reduced_rows": list(rows) if rows else [0, N], "reserve_cus": reserve, "reserve_cus_why": reserve_why,
                  "allreduce_bytes": nbytes, "allreduce_ms_alone": ar_ms,
                  "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9 if world > 1 else None,
                  "gridding_ms_per_step": float(np.mean(ker_ms) + np.mean(pre_ms)),
