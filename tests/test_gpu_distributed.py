@@ -99,11 +99,25 @@ def test_cabi_communicator_rank_form_and_single_process_form():
             Comm.single_process(2, [0, 0])
         except gridhip.GridHipError as e:
             bad = e.code
-        print(json.dumps({"e_rank": e_rank, "e_single": e_single, "sizes": sizes, "same": same, "bad": bad}))
+        # a shard whose records are lost (test hook fault_inject on the communicator's own context): the synchronous
+        # form reports the inconsistency instead of handing back an incomplete grid, and leaves the caller's grid alone
+        import ctypes as C
+        comm2 = Comm.single_process(1)
+        h = comm2._lib.gridhip_comm_ctx(comm2._h, 0)
+        assert comm2._lib.gridhip_set_option(C.c_void_p(h), b"fault_inject", 4000) == 0
+        G2 = start.copy()
+        lost = None
+        try:
+            comm2.convgrid2(gcf, G2, (us[1], vs[1], None), wb, vis)
+        except gridhip.GridHipError as e:
+            lost = (e.code, "consistency" in str(e), bool(np.array_equal(G2, start)))
+        comm2.close()
+        print(json.dumps({"e_rank": e_rank, "e_single": e_single, "sizes": sizes, "same": same, "bad": bad, "lost": lost}))
         dist.destroy_process_group()
     """)
     assert rec["e_rank"] < 1e-10 and rec["e_single"] < 1e-10
     assert rec["sizes"] == [1, 1] and rec["same"] and rec["bad"] == -1
+    assert rec["lost"] == [-1, True, True]
 
 
 def test_cabi_rows_reduce_scatter_and_side_stream_with_one_rank():

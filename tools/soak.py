@@ -18,8 +18,12 @@ import gridhip
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="cfg3")
 ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--support", type=int, default=0, help="another square support on the workload's shape (17 .. 32: parts of the tap list)")
+ap.add_argument("--nvis", type=int, default=0)
 a = ap.parse_args()
 n, N, W, Q, S = bench.WORKLOADS[a.workload]
+S = a.support or S
+n = a.nvis or n
 dev = torch.device("cuda:0")
 ctx = gridhip.Context(0)
 gcf = bench.synth_kernels(W, Q, S, dev)
@@ -39,7 +43,8 @@ scale = (vis.abs() * gcf.abs().sum(dim=(3, 4))[wb, yf, xf]).sum().item()
 del ks
 G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
 out = torch.empty(n, dtype=torch.complex128, device=dev)
-sets = [{}, {"wgroups": 4}, {"chunk": 4096}, {"prepass": 6}, {"tile": 64}, {"wtable": 1}]
+sets = [{}, {"wgroups": 4}, {"chunk": 4096}, {"prepass": 6}, {"tile": 64}, {"wtable": 1}, {"bigtile": 1}, {"reserve_cus": 32},
+        {"bigtile": 1, "wgroups": 4}]
 worst, t0 = 0.0, time.time()
 dref = None
 for step in range(a.steps):
