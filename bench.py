@@ -70,11 +70,16 @@ def parse_args(argv=None):
                          "(gridhip_comm_*, ncclAllReduce); cabi-rs = the same with ncclReduceScatter + ncclAllGather")
     ap.add_argument("--reduce-rows", default="auto", choices=["auto", "all"],
                     help="auto: the stream is mirrored (v >= 0), so only the rows it can touch are reduced (half the bytes)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "side", "inline"],
+                    help="N > 1: where the per-step collective runs: side = on a side stream beside the next step's gridding "
+                         "(with 32 CUs reserved for it unless --reserve-cus says otherwise); inline = right behind the "
+                         "step's gridding, no overlap and no reservation; auto = an untimed pass measures the collective "
+                         "alone and one gridding step and takes side when the collective is longer than 1/6 of the step "
+                         "(tools/pipeline_overlap_probe.py: below that the reservation costs more than it hides)")
     ap.add_argument("--reserve-cus", type=int, default=-1,
-                    help="compute units the persistent tile kernel leaves free for the collective's kernel (-1 = auto: N > 1 "
-                         "measures the collective alone in an untimed pass and reserves 32 - one per shader engine of every "
-                         "XCD, profiles/r03_reserve_cus.txt - when it takes more than the 10 %% of the gridding step the "
-                         "reservation costs; 0 otherwise)")
+                    help="compute units the persistent tile kernel leaves free for a side-stream collective's kernel (-1 = "
+                         "auto: 32 - one per shader engine of every XCD, profiles/r03_reserve_cus.txt - when the collective "
+                         "overlaps, else 0)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EEDC0DE)
     ap.add_argument("--grids", type=int, default=0,
                     help="N = 1: how many zeroed grids the steps rotate over (0 = one per step, at most 16; 1 = every step "
@@ -479,7 +484,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import gridhip
-    from gridhip.distributed import Comm, OverlappedCommReducer, OverlappedGridReducer, mirrored_first_row, shard_bounds
+    from gridhip.distributed import (Comm, InlineGridReducer, OverlappedCommReducer, OverlappedGridReducer,
+                                     mirrored_first_row, shard_bounds)
     n, N, W, Q, S = WORKLOADS[args.workload]
     if args.nvis:
         n = args.nvis
@@ -499,13 +505,7 @@ def main():
         ctx.set_option(k, int(val))
     if aw:
         ctx.set_option("aw_cache", args.aw_cache)
-    # CUs the persistent tile kernel leaves free for the collective's kernel: given, or (N > 1, -1) decided in the
-    # warm-up below from what the collective and the reservation each cost
-    reserve = args.reserve_cus if args.reserve_cus >= 0 else 0
-    reserve_why = "given" if args.reserve_cus >= 0 else "auto: one GPU"
-    if reserve:
-        ctx.set_option("reserve_cus", reserve)
-
+    reserve = max(args.reserve_cus, 0)  # (N > 1: decided below, together with where the collective runs)
     gcf = synth_kernels(W, Q, S, device)
     if aw:
         akerns = synth_akernels(AW_ANTENNAS, S, device)
@@ -525,13 +525,59 @@ def main():
     # and are left out of the collective.
     rows = (mirrored_first_row(N, S), N) if (args.reduce_rows == "auto" and not aw) else None
     red = comm = None
+    schedule = None
     if dist is not None:
-        if args.collective == "torch":
-            red = OverlappedGridReducer(bufs, rows=rows)
-        else:
+        if args.collective != "torch":
             comm = Comm.from_torch(ctx)
             comm.set_option("collective", 1 if args.collective == "cabi-rs" else 0)
+        part0 = bufs[0] if rows is None else bufs[0][rows[0]:rows[1]]
+
+        def collective_once():
+            if comm is None:
+                dist.all_reduce(torch.view_as_real(part0))
+            elif rows is None:
+                comm.allreduce_grid(bufs[0])
+            else:
+                comm.allreduce_grid_rows(bufs[0], *rows)
+
+        # Where the collective runs.  Beside a persistent tile kernel that occupies every CU, a collective on a side
+        # stream starts when that kernel ends unless CUs are reserved for it, and reserving 32 (one per shader engine of
+        # every XCD: what a many-work-group kernel needs to start) costs the gridding 10 %, plus ~0.4 of the collective
+        # that still shows (tools/pipeline_overlap_probe.py, profiles/r03_pipeline_overlap.txt): overlapping pays when
+        # the collective is longer than about 1/6 of the gridding step; a shorter one is cheapest right behind the
+        # step's gridding.  auto: an untimed pass measures both, the slowest rank decides for all.
+        ctx.enable_timing(True)
+        ctx._use_torch_stream()
+        ctx.convgrid2(gcf, bufs[0], (u, v, None), wb, vis) if not aw else ctx.convgrid4(gcf, akerns, bufs[0], (u, v, None), (wb, a1, a2), vis)
+        torch.cuda.synchronize()
+        t_grid = sum(ctx.timing(0)[1:3])
+        dist.barrier()
+        collective_once()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            collective_once()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([t_grid, e0.elapsed_time(e1) / 3], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_grid, t_coll = float(t[0].item()), float(t[1].item())
+        side = args.overlap == "side" or (args.overlap == "auto" and t_coll > t_grid / 6.0)
+        if args.reserve_cus < 0:
+            reserve = 32 if side else 0
+        schedule = {"collective_runs": "side stream, beside the next step's gridding" if side else "in line, behind the step's gridding",
+                    "chosen_by": args.overlap, "measured_collective_ms": t_coll, "measured_gridding_ms": t_grid,
+                    "rule": "side when the collective alone takes more than 1/6 of a gridding step"}
+        if side and comm is None:
+            red = OverlappedGridReducer(bufs, rows=rows)
+        elif side:
             red = OverlappedCommReducer(comm, bufs, rows=rows)
+        else:
+            red = InlineGridReducer(bufs, rows=rows, comm=comm)
+        for b_ in bufs:
+            b_.zero_()
+    if reserve:
+        ctx.set_option("reserve_cus", reserve)
     counter = [0]
 
     def step():
@@ -549,33 +595,6 @@ def main():
             red.end(i)
 
     ctx.enable_timing(True)
-    if dist is not None and args.reserve_cus < 0:
-        # Untimed tuning pass: reserving 32 CUs (one per shader engine of every XCD: what lets a many-work-group kernel
-        # start beside the tile kernel, profiles/r03_reserve_cus.txt) costs the gridding ~10 %; it pays when the
-        # collective, which otherwise runs after the tile kernel, takes longer than that.  Both are measured here, the
-        # slowest rank decides for all.
-        step()
-        red.finish()
-        torch.cuda.synchronize()
-        t_grid = sum(ctx.timing(0)[1:3])
-        dist.barrier()
-        part0 = bufs[0] if rows is None else bufs[0][rows[0]:rows[1]]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist.all_reduce(torch.view_as_real(part0))
-        e0.record()
-        for _ in range(3):
-            dist.all_reduce(torch.view_as_real(part0))
-        e1.record()
-        torch.cuda.synchronize()
-        t = torch.tensor([t_grid, e0.elapsed_time(e1) / 3], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_grid, t_coll = float(t[0].item()), float(t[1].item())
-        reserve = 32 if t_coll > 0.10 * t_grid else 0
-        reserve_why = (f"auto: collective alone {t_coll:.2f} ms against 10 % of the {t_grid:.2f} ms gridding step "
-                       f"(what reserving 32 CUs costs)")
-        ctx.set_option("reserve_cus", reserve)
-        counter[0] = 0
-        passes[:] = [0] * nbuf
     for _ in range(args.warmup):
         step()
     if red:
@@ -652,9 +671,8 @@ def main():
             else:
                 comm.allreduce_grid_rows(G, *rows)
 
-        if comm:
-            red.close()  # (the communicator's collectives go back to the context's stream = torch's current stream)
-            ctx._use_torch_stream()
+        red.close()  # (the communicator's collectives go back to the context's stream = torch's current stream)
+        ctx._use_torch_stream()
         for _ in range(2):
             one()
         torch.cuda.synchronize()
@@ -668,7 +686,7 @@ def main():
         ar_ms = e0.elapsed_time(e1) / 5
         nbytes = int(part.numel() * 16)
         multi = {"rccl_ranks": dist.get_world_size(), "collective": args.collective, "scaling": args.scaling,
-                 "reduced_rows": list(rows) if rows else [0, N], "reserve_cus": reserve, "reserve_cus_why": reserve_why,
+                 "reduced_rows": list(rows) if rows else [0, N], "reserve_cus": reserve, "schedule": schedule,
                  "allreduce_bytes": nbytes, "allreduce_ms_alone": ar_ms,
                  "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9 if world > 1 else None,
                  "gridding_ms_per_step": float(np.mean(ker_ms) + np.mean(pre_ms)),
@@ -762,8 +780,8 @@ def main():
                 "workload": what,
                 "name": args.workload,
                 "vis_per_gpu": n_rank, "vis_total": n_total, "scaling": args.scaling, "seed": args.seed, "grid": N, "w_planes": W, "support": S, "oversample": Q,
-                "parallelism": f"vis-sharded x{world}" + (f" + RCCL fp64 grid sum per step ({args.collective}; side stream, "
-                                                          f"overlapped with the next step's gridding; {reserve} CUs reserved)"
+                "parallelism": f"vis-sharded x{world}" + (f" + RCCL fp64 grid sum per step ({args.collective}; "
+                                                          f"{schedule['collective_runs']}; {reserve} CUs reserved)"
                                                           if world > 1 else ""),
                 "scaling_note": ("weak: one global counter-based stream of n_gpus x vis_per_gpu visibilities, rank r grids "
                                  "[r, r + 1) x vis_per_gpu of it; value = vis_total / step time" if args.scaling == "weak" else

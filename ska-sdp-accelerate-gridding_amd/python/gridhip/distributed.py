@@ -84,6 +84,41 @@ class OverlappedGridReducer:
                 self.work[k] = None
         self.torch.cuda.current_stream().wait_stream(self.comm)
 
+    def close(self):
+        self.finish()
+
+
+class InlineGridReducer:
+    """The same begin(i) / end(i) / finish() protocol without overlap: step i's collective is enqueued right behind its
+    gridding, on the gridding stream (libgridhip's communicator) or with the gridding stream waiting for it
+    (torch.distributed), and the next step starts when it is done.  What a SHORT collective wants: beside a persistent
+    tile kernel that occupies every CU a side-stream collective does not start before that kernel ends unless CUs are
+    reserved for it (tools/pipeline_overlap_probe.py), and reserving them costs the gridding 10 %; a collective that
+    takes less than that is cheapest in line."""
+
+    def __init__(self, grids, group=None, rows=None, comm=None):
+        self.grids, self.group, self.rows, self.c = grids, group, rows, comm
+
+    def begin(self, i, zero=True):
+        if zero:
+            self.grids[i % len(self.grids)].zero_()
+        return self.grids[i % len(self.grids)]
+
+    def end(self, i):
+        g = self.grids[i % len(self.grids)]
+        if self.c is None:
+            allreduce_grid(g, self.group, rows=self.rows)
+        elif self.rows is None:
+            self.c.allreduce_grid(g)
+        else:
+            self.c.allreduce_grid_rows(g, *self.rows)
+
+    def finish(self):
+        pass
+
+    def close(self):
+        pass
+
 
 class OverlappedCommReducer:
     """OverlappedGridReducer over libgridhip's own communicator (Comm, rank form) instead of torch.distributed: the

@@ -189,7 +189,8 @@ def test_bench_multi_gpu_branch_with_one_rank(collective):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(GRIDHIP_BENCH_FORCE_DIST="1", MASTER_PORT="29535")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nvis",
-                          "3000000", "--no-cpu", "--collective", collective, "--reserve-cus", "16"], capture_output=True, text=True,
+                          "3000000", "--no-cpu", "--collective", collective, "--reserve-cus", "16", "--overlap",
+                          "auto" if collective == "cabi" else "side"], capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-4000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -198,6 +199,9 @@ def test_bench_multi_gpu_branch_with_one_rank(collective):
     assert rec["check"]["rel_err"] <= 1e-10 and rec["multi_gpu"]["check_rel_err"] == rec["check"]["rel_err"]
     assert rec["multi_gpu"]["reduced_rows"] == [4096 // 2 - 15 // 2 - 1, 4096] and rec["multi_gpu"]["reserve_cus"] == 16
     assert rec["scaling"] == "weak" and rec["multi_gpu"]["scaling"] == "weak"
+    sch = rec["multi_gpu"]["schedule"]  # (one rank: the collective costs nothing, auto puts it in line)
+    assert sch["collective_runs"].startswith("in line" if collective == "cabi" else "side stream")
+    assert sch["measured_gridding_ms"] > 0 and sch["measured_collective_ms"] >= 0
     assert 0 < rec["roofline"]["frac"] <= 1 and 0 < rec["roofline"]["lds_floor_frac"] <= 1
     assert rec["roofline"]["bound"] == "lds_atomic" and 1.0 < rec["roofline"]["clock_GHz"] < 2.6
 
