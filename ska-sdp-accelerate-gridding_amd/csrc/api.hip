@@ -121,7 +121,7 @@ int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64
         Prep q;
         const int P = py * px;
         q.nrec = n * P;
-        if (make_geom(ctx, H, Wd, W, Q, sub, sub, q.nrec, &q.g, &q.block, &q.lds) == GRIDHIP_OK) {
+        if (make_geom(ctx, H, Wd, W, Q, sub, sub, q.nrec, &q.g, &q.block, &q.lds, P) == GRIDHIP_OK) {
             q.g.fgh = (int32_t)gh;
             q.g.fgw = (int32_t)gw;
             q.g.py = py;

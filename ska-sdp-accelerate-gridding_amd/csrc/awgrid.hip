@@ -444,7 +444,7 @@ int gridhip_awgrid_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, double *grid, in
         Geom g;
         int block;
         size_t lds;
-        int rc = make_geom(ctx, H, Wd, 1, Q, S, S, batch, &g, &block, &lds);
+        int rc = make_geom(ctx, H, Wd, 1, Q, S, S, batch, &g, &block, &lds, 0);  // (no big-tile form of the aw tile kernel)
         ctx->opt.wgroups = keep_w;
         GH_CHECK(rc);
         g.per_vis = 1;

@@ -206,8 +206,10 @@ static inline void mark(gridhip_ctx *ctx, int i)
 }
 
 // geometry / option resolution (host)
+// parts: the kernel slices per (plane, sub-pixel offset) the tap-reusing kernel's sort will count (sub-footprints: P; 1
+// otherwise) - the big tile must leave room for that histogram; 0 = never a big tile (aw gridders)
 int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh,
-              int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes);
+              int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes, int parts = 1);
 // ---- device-side coordinate math ---------------------------------------------------------
 // frac_coord of src/Gridding.hs:126-140, bit-for-bit with the oracle: contraction is switched
 // off for this block so `halfn + p*n` stays a rounded multiply followed by a rounded add

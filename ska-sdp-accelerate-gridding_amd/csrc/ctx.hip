@@ -73,8 +73,25 @@ Tables tables_of(gridhip_ctx *ctx, const Geom &g)
     return t;
 }
 
+static int make_geom1(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh, int64_t gw, int64_t n,
+                      Geom *g, int *block, size_t *lds_bytes, int parts);
+
 int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh,
-              int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes)
+              int64_t gw, int64_t n, Geom *g, int *block, size_t *lds_bytes, int parts)
+{
+    GH_CHECK(make_geom1(ctx, H, Wd, W, Q, gh, gw, n, g, block, lds_bytes, parts));
+    if (g->imoff > 0) {
+        // the big tile was sized with an estimate of the sort's histogram (8 w-groups); with the groups actually chosen
+        // it must still fit beside the two planes, or the tap-reusing kernel would refuse the geometry: then the classic tile
+        const int64_t planes = (W + g->ngroups - 1) / g->ngroups + 1;
+        const size_t hist = (size_t)((planes * Q * Q * parts + 1 + 3) & ~(int64_t)3) * 4;
+        if (2 * (size_t)g->imoff + hist + 128 > (size_t)ctx->max_lds) GH_CHECK(make_geom1(ctx, H, Wd, W, Q, gh, gw, n, g, block, lds_bytes, 0));
+    }
+    return GRIDHIP_OK;
+}
+
+static int make_geom1(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64_t gh, int64_t gw, int64_t n,
+                      Geom *g, int *block, size_t *lds_bytes, int parts)
 {
     if (H <= 0 || Wd <= 0 || W <= 0 || Q <= 0 || gh <= 0 || gw <= 0)
         return fail(ctx, GRIDHIP_EINVAL, "non-positive dimension");
@@ -108,7 +125,7 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     // ("bigtile": 0 = auto - where items are sparse, i.e. fewer than two visibilities per kernel slice and work item with
     // the classic tile: measured +2 % on the 8192^2 share of configuration 5, -4 % where the LDS unit binds; 1 = on;
     // 2 = off)
-    const bool bt_ok = ctx->opt.bigtile != 2 && ctx->opt.tile == 0 && ctx->opt.tile_x == 0 && gh == gw && gh >= 5 && gh <= 32;
+    const bool bt_ok = parts > 0 && ctx->opt.bigtile != 2 && ctx->opt.tile == 0 && ctx->opt.tile_x == 0 && gh == gw && gh >= 5 && gh <= 32;
     auto plane_for = [&](int tx, int ty) {
         return (size_t)lds_pitch(tx + (int)gw - 1, (int)gw) * (size_t)(ty + (int)gh - 1) * 8;
     };
@@ -117,7 +134,10 @@ int make_geom(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int
     // 32 cells (bank-conflict rule, lds_pitch), so the candidates are the widest tile of each pitch with the
     // tallest height that fits: 65 x 89 for a 15 x 15 kernel, against 64 x 64 as a square power of two.
     auto largest_tile = [&](bool big, int *otx, int *oty) {
-        const size_t hist_room = big ? (size_t)(((W + 7) / 8 + 2) * Q * Q) * 4 + 1024 : 24576;  // the sort's histogram
+        // the sort's histogram: one counter per slice of a w-group (8 groups, or what option "wgroups" says)
+        const int64_t ng_est = ctx->opt.wgroups ? ctx->opt.wgroups : (W >= 8 ? 8 : 1);
+        const size_t hist_need = (size_t)(((W + ng_est - 1) / ng_est + 2) * Q * Q * (parts > 0 ? parts : 1)) * 4 + 1024;
+        const size_t hist_room = big ? hist_need : (hist_need > 24576 && hist_need < 65536 * 4 ? hist_need : 24576);
         const size_t plane_cap = big ? lds_cap : 65528;
         size_t best = 0;
         if (hist_room + 8192 > lds_cap) return best;

@@ -863,3 +863,24 @@ def test_last_path_reports_which_gridder_ran(ctx):
     assert run(15, 15, 500) == 3                     # too few visibilities per work item for the sort to pay
     assert run(15, 15, 60000, sort=2) == 3
     assert run(15, 15, 60000, variant=1) == 4
+
+
+@pytest.mark.parametrize("opts", [{"wgroups": 4}, {"wgroups": 1}, {"wgroups": 16}, {"wgroups": 2, "subfoot": 1}])
+def test_bigtile_keeps_the_fast_path_whatever_the_wgroups(ctx, oracle, opts):
+    """The big tile is sized around the sort's histogram, whose length depends on the number of w-groups (and, for
+    sub-footprints, parts): a geometry whose histogram would not fit beside the big planes must fall back to the classic
+    tile, not off the tap-reusing kernel (round 3 found wgroups = 4 on the 8192^2 grid taking the general kernel)."""
+    N, W, Q, S, n = 3200, 64, 8, 17, 600_000
+    gcf, u, v, wb, vis = case(77 + len(opts), N, N, W, Q, S, S, n, spread=0.5)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
+    try:
+        ctx.set_option("bigtile", 1)
+        ctx.set_option("sort", 1)
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+        path = ctx.get_option("last_path")
+    finally:
+        for k in ("bigtile", "sort", "wgroups", "subfoot"):
+            ctx.set_option(k, 0)
+    assert path in (1, 2) and rel(got, ref) < TOL
