@@ -468,6 +468,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    # (test hooks: GRIDHIP_BENCH_SHARE_GPU=1 puts every rank on device 0 and GRIDHIP_BENCH_BACKEND=gloo replaces RCCL,
+    # which refuses two ranks on one device, by gloo's host-staged collectives - how a one-GPU box runs this file with
+    # two real ranks, tests/test_gpu_distributed.py)
+    if os.environ.get("GRIDHIP_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:  # (counting devices does not initialise the GPU)
         raise SystemExit(f"rank {rank}: needs GPU {local_rank}, this machine has {torch.cuda.device_count()}")
     if not torch.cuda.is_available():
@@ -481,7 +486,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("GRIDHIP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import gridhip
     from gridhip.distributed import (Comm, InlineGridReducer, OverlappedCommReducer, OverlappedGridReducer,

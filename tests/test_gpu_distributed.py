@@ -311,3 +311,28 @@ def test_two_ranks_share_one_gpu_over_gloo():
     for so, _ in outs:
         rec = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
         assert len(rec["errs"]) == 4 and max(rec["errs"]) < 1e-10 and rec["errors"] == 0
+
+
+@pytest.mark.parametrize("scaling,overlap", [("weak", "side"), ("strong", "inline"), ("strong", "auto")])
+def test_bench_with_two_real_ranks_sharing_the_gpu(scaling, overlap):
+    """bench.py itself with two rank processes (both on cuda:0, gloo's host-staged collectives in place of RCCL, which
+    refuses two ranks on one device): the global stream sharded weak and strong, the untimed scheduling pass, the
+    side-stream and in-line reducers with the rows-only reduction, and the line's own verdict - the REDUCED grid of two
+    real shards against the checksum all-reduced over the ranks (a rank gridding the wrong range, a buffer reduced
+    twice or cleared late, rows skipped that were not zero: all show there)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GRIDHIP_BENCH_SHARE_GPU="1", GRIDHIP_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--nvis", "3000000", "--scaling", scaling, "--overlap", overlap], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and rec["errors"] == 0
+    assert rec["config"]["vis_total"] == (6000000 if scaling == "weak" else 3000000)
+    assert rec["config"]["vis_per_gpu"] == (3000000 if scaling == "weak" else 1500000)
+    assert rec["check"]["rel_err"] <= 1e-10 and rec["multi_gpu"]["check_rel_err"] <= 1e-10
+    assert rec["check"]["cells_nonzero"] > 100000
+    m = rec["multi_gpu"]
+    assert m["rccl_ranks"] == 2 and m["reduced_rows"] == [2040, 4096] and m["allreduce_bytes"] == (4096 - 2040) * 4096 * 16
+    assert m["schedule"]["collective_runs"].startswith("side" if overlap == "side" else "in line") or overlap == "auto"
+    assert m["reserve_cus"] == (32 if m["schedule"]["collective_runs"].startswith("side") else 0)
