@@ -92,9 +92,10 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
     // taps in registers.  One record per visibility, one tile with the full support's halo, no padding - against
     // sub-footprints (api.hip), which give every visibility one record per spatial part.  Parts 0 .. REM-1 have KST
     // steps, the others KST - 1 (all KST when REM = 0); FP = 1 up to 16 x 16.
-    // (five steps - 17 x 17 - still fit one part when gridding: 20 VGPRs per tap set; its units of 3 + 2 steps were
-    // too short to cover the taps' latency: 16.0 -> ? ms)
-    constexpr int FP = (NSTEP_ALL <= 5 && !DEGRID) ? 1 : (NSTEP_ALL + 3) / 4;
+    // (gridding has the registers for five steps per tap set - 20 VGPRs, 118 in all, no spills - and fewer, longer
+    // parts cover the taps' latency better: 17 x 17 as one part of five steps 16.0 -> 13.2 ms against parts of 3 + 2)
+    constexpr int MAXST = DEGRID ? 4 : 5;
+    constexpr int FP = (NSTEP_ALL + MAXST - 1) / MAXST;
     constexpr int KST = (NSTEP_ALL + FP - 1) / FP;
     constexpr int REM = NSTEP_ALL % FP;
     constexpr int PBASE = NSTEP_ALL / FP;                       // steps of the shorter parts
