@@ -225,7 +225,8 @@ static int make_geom1(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_
     set_div_magic(g);
     // which table of walker weights (tile_sorted.hip): the steeper one where the LDS unit binds - supports 15 and 16 with two
     // or more visibilities per slice and tile; measured per support, option "wtable" forces 1 = flat, 2 = steep
-    g->dense = ctx->opt.wtable ? (ctx->opt.wtable == 2 ? 1 : 0) : (gh >= 15 && n >= 2 * (int64_t)g->ntiles * W * Q * Q) ? 1 : 0;
+    g->dense = ctx->opt.wtable ? (ctx->opt.wtable >= 3 ? 2 : ctx->opt.wtable == 2 ? 1 : 0)
+                               : (gh >= 15 && n >= 2 * (int64_t)g->ntiles * W * Q * Q) ? 1 : (g->imoff > 0 && gh == 15) ? 2 : 0;
 
     int chunk = (int)ctx->opt.chunk;
     if (chunk == 0) chunk = 8192;

@@ -47,8 +47,10 @@ constexpr int SORTED_IM_OFF = 65528;  // largest multiple of 8 that a DS instruc
 // cfg3), and the flatter 1.55 / 1.14 / 0.71 / 0.48 where items are sparse and the walkers wait for taps instead
 // (Geom.dense = 0: fewer than two visibilities per slice and tile - the steep table costs 0.5 % there - and supports
 // below 15, measured 1 - 2 % faster with the flat one).
-__device__ const int cut15[2][16] = {{0, 106, 211, 317, 422, 500, 578, 655, 733, 781, 829, 877, 926, 958, 991, 1024},
-                                     {0, 108, 221, 329, 434, 513, 596, 677, 754, 800, 852, 898, 943, 969, 998, 1024}};
+// [2]: the big tile on sparse items (Geom.dense = 2), re-weighted the same way on the 8192^2 share of configuration 5
+__device__ const int cut15[3][16] = {{0, 106, 211, 317, 422, 500, 578, 655, 733, 781, 829, 877, 926, 958, 991, 1024},
+                                     {0, 108, 221, 329, 434, 513, 596, 677, 754, 800, 852, 898, 943, 969, 998, 1024},
+                                     {0, 100, 202, 303, 401, 480, 562, 641, 718, 769, 824, 875, 925, 957, 992, 1024}};
 
 struct SortedItem {
     int32_t valid, tile, grp, staged;
@@ -791,6 +793,15 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
         else                                                                        \
             GH_LAUNCH(S_, false);                                                   \
         break;
+#define GH_ABL_BT(A_)                                                                                            \
+    if (g.gh == 15 && !degrid && g.imoff > 0 && g.dbg == A_) {                                                   \
+        GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<15, false, A_, false, true>));                           \
+        hipLaunchKernelGGL((tile_grid_sorted_kernel<15, false, A_, false, true>), gr, bl, lds_bytes, ctx->stream, g, recs, \
+                           t.bin_start, t.work_start, (const double2 *)gcf, (double2 *)vis, grid, nkeys, batch, \
+                           t.scalars, svals, smo);                                                               \
+        GH_CHECK_HIP(ctx, hipGetLastError());                                                                    \
+        return GRIDHIP_OK;                                                                                       \
+    }
 #define GH_ABL(A_)                                                                                               \
     if (g.gh == 15 && !degrid && g.imoff == 0 && g.dbg == A_) {                                                  \
         GH_CHECK(raise_lds(ctx, tile_grid_sorted_kernel<15, false, A_>));                                        \
@@ -801,9 +812,10 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
         return GRIDHIP_OK;                                                                                       \
     }
 #ifdef GRIDHIP_TUNING  // ablation / phase-profile instantiations: tuning builds only (make tuning)
-    GH_ABL(1) GH_ABL(2) GH_ABL(3) GH_ABL(4) GH_ABL(5) GH_ABL(7) GH_ABL(8) GH_ABL(15) GH_ABL(16)
+    GH_ABL(1) GH_ABL(2) GH_ABL(3) GH_ABL(4) GH_ABL(5) GH_ABL(7) GH_ABL(8) GH_ABL(15) GH_ABL(16) GH_ABL_BT(16)
 #endif
 #undef GH_ABL
+#undef GH_ABL_BT
     switch (g.gh) {
         GH_CASE(5) GH_CASE(6) GH_CASE(7) GH_CASE(8) GH_CASE(9) GH_CASE(10) GH_CASE(11) GH_CASE(12) GH_CASE(13)
         GH_CASE(14) GH_CASE(15) GH_CASE(16)
