@@ -11,7 +11,7 @@ bash tools/profile.sh r03_cfg3 > $OUT/profile_cfg3.log 2>&1; echo "profile cfg3 
 bash tools/profile.sh r03_cfg5 --workload cfg5 > $OUT/profile_cfg5.log 2>&1; echo "profile cfg5 rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03_cfg4/trace -- python3 bench.py --workload cfg4 --no-cpu --steps 5 --warmup 2 > $OUT/prof_cfg4.log 2>&1; echo "trace cfg4 rc=$?"
 python tools/phase_profile.py --workload=cfg3 > $OUT/phase_cfg3.log 2>&1; echo "phase cfg3 rc=$?"
-python tools/phase_profile.py --workload=cfg5 bigtile=2 > $OUT/phase_cfg5.log 2>&1; echo "phase cfg5 rc=$?"
+python tools/phase_profile.py --workload=cfg5 "" bigtile=2 > $OUT/phase_cfg5.log 2>&1; echo "phase cfg5 rc=$?"
 for WL in cfg3 cfg2 cfg5 cfg4; do
   python bench.py --workload $WL > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; echo "bench $WL rc=$?"
 done
