@@ -132,3 +132,57 @@ def test_two_rank_gloo_bench_sharding_rows_and_checksum(scaling):
     res = [q.get(timeout=10) for _ in range(2)]
     for _, rel, err in res:
         assert rel < 1e-12 and err < 1e-12
+
+
+def _inline_worker(rank, world, port, q):
+    """InlineGridReducer (the schedule bench.py takes for short collectives) on two gloo ranks with CPU tensors: three
+    steps over two buffers, rows-only reduction, every reduced grid against the one-process grid of the whole stream."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "ska-sdp-accelerate-gridding_amd", "python"))
+    import torch
+    import torch.distributed as dist
+    import bench
+    from gridhip.distributed import InlineGridReducer, mirrored_first_row, shard_bounds
+    from oracle import gridref_c
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, W, Q, S, n = 160, 4, 4, 7, 4001
+    dev = torch.device("cpu")
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    bufs = [torch.zeros((N, N), dtype=torch.complex128) for _ in range(2)]
+    red = InlineGridReducer(bufs, rows=(mirrored_first_row(N, S), N))
+    errs = []
+    for i in range(3):
+        seed = 100 + i
+        lo, hi = shard_bounds(n, world, rank)
+        u, v, wb, vis = bench.synth_vis(hi - lo, N, W, S, seed, dev, lo=lo)
+        g = red.begin(i)
+        gridref_c.convgrid2(gcf.numpy(), g.numpy(), u.numpy(), v.numpy(), wb.numpy(), vis.numpy())
+        red.end(i)
+        U, V, WB, VIS = bench.synth_vis(n, N, W, S, seed, dev)
+        ref = gridref_c.convgrid2(gcf.numpy(), np.zeros((N, N), dtype=np.complex128), U.numpy(), V.numpy(), WB.numpy(), VIS.numpy())
+        errs.append(float(np.abs(g.numpy() - ref).max() / np.abs(ref).max()))
+    red.finish()
+    red.close()
+    q.put((rank, max(errs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_inline_reducer():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_inline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, "worker failed"
+    for _ in range(2):
+        assert q.get(timeout=10)[1] < 1e-12
