@@ -71,15 +71,17 @@ def parse_args(argv=None):
     ap.add_argument("--reduce-rows", default="auto", choices=["auto", "all"],
                     help="auto: the stream is mirrored (v >= 0), so only the rows it can touch are reduced (half the bytes)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "side", "inline"],
-                    help="N > 1: where the per-step collective runs: side = on a side stream beside the next step's gridding "
-                         "(with 32 CUs reserved for it unless --reserve-cus says otherwise); inline = right behind the "
-                         "step's gridding, no overlap and no reservation; auto = an untimed pass measures the collective "
-                         "alone and one gridding step and takes side when the collective is longer than 1/6 of the step "
-                         "(tools/pipeline_overlap_probe.py: below that the reservation costs more than it hides)")
+                    help="N > 1: where the per-step collective runs: side = on a side stream beside the next step's gridding; "
+                         "inline = right behind the step's gridding, no overlap; auto = an untimed pass runs a few steps "
+                         "in line and on the side stream (plain, with 64 CUs yielding, with 32 CUs reserved) and the "
+                         "fastest schedule - max over ranks - is used (tools/pipeline_overlap_probe.py)")
     ap.add_argument("--reserve-cus", type=int, default=-1,
-                    help="compute units the persistent tile kernel leaves free for a side-stream collective's kernel (-1 = "
-                         "auto: 32 - one per shader engine of every XCD, profiles/r03_reserve_cus.txt - when the collective "
-                         "overlaps, else 0)")
+                    help="compute units the persistent tile kernel leaves idle for a side-stream collective's kernel (-1 = "
+                         "measured, see --overlap; 32 = one per shader engine of every XCD, profiles/r03_reserve_cus.txt)")
+    ap.add_argument("--yield-cus", type=int, default=-1,
+                    help="compute units on which the tile kernel runs short-lived work-groups instead of persistent ones, so "
+                         "that a kernel queued on another stream gets them within a few hundred microseconds (-1 = "
+                         "measured, see --overlap; multiples of 32)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EEDC0DE)
     ap.add_argument("--grids", type=int, default=0,
                     help="N = 1: how many zeroed grids the steps rotate over (0 = one per step, at most 16; 1 = every step "
@@ -515,6 +517,9 @@ def main():
     if aw:
         ctx.set_option("aw_cache", args.aw_cache)
     reserve = max(args.reserve_cus, 0)  # (N > 1: decided below, together with where the collective runs)
+    yield_cus = max(args.yield_cus, 0)
+    if yield_cus:
+        ctx.set_option("yield_cus", yield_cus)
     gcf = synth_kernels(W, Q, S, device)
     if aw:
         akerns = synth_akernels(AW_ANTENNAS, S, device)
@@ -549,44 +554,72 @@ def main():
             else:
                 comm.allreduce_grid_rows(bufs[0], *rows)
 
-        # Where the collective runs.  Beside a persistent tile kernel that occupies every CU, a collective on a side
-        # stream starts when that kernel ends unless CUs are reserved for it, and reserving 32 (one per shader engine of
-        # every XCD: what a many-work-group kernel needs to start) costs the gridding 10 %, plus ~0.4 of the collective
-        # that still shows (tools/pipeline_overlap_probe.py, profiles/r03_pipeline_overlap.txt): overlapping pays when
-        # the collective is longer than about 1/6 of the gridding step; a shorter one is cheapest right behind the
-        # step's gridding.  auto: an untimed pass measures both, the slowest rank decides for all.
+        # Where the collective runs is MEASURED, not assumed (tools/pipeline_overlap_probe.py, reserve_cus_probe.py and
+        # profiles/r03_pipeline_overlap.txt, r03_yield_cus.txt show why no rule is safe): a collective's kernel issued on a
+        # side stream behind the step's tile kernel takes its CUs at the kernel boundary, as that kernel's work-groups
+        # retire, and runs beside the next step's gridding - but a SECOND kernel of the same collective (reduce-scatter
+        # then all-gather) becomes ready in the middle of a persistent tile kernel that occupies every CU and then
+        # waits for its end, unless CUs come free: "yield_cus" (64 CUs run short-lived work-groups, +0.7 % on the
+        # gridding) or "reserve_cus" (32 CUs left idle, +10 %).  A short collective can be cheapest in line.  auto: an
+        # untimed pass runs a few steps of each schedule; the slowest rank's time decides for all ranks.
         ctx.enable_timing(True)
         ctx._use_torch_stream()
-        ctx.convgrid2(gcf, bufs[0], (u, v, None), wb, vis) if not aw else ctx.convgrid4(gcf, akerns, bufs[0], (u, v, None), (wb, a1, a2), vis)
-        torch.cuda.synchronize()
-        t_grid = sum(ctx.timing(0)[1:3])
-        dist.barrier()
-        collective_once()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            collective_once()
-        e1.record()
-        torch.cuda.synchronize()
-        t = torch.tensor([t_grid, e0.elapsed_time(e1) / 3], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_grid, t_coll = float(t[0].item()), float(t[1].item())
-        side = args.overlap == "side" or (args.overlap == "auto" and t_coll > t_grid / 6.0)
-        if args.reserve_cus < 0:
-            reserve = 32 if side else 0
-        schedule = {"collective_runs": "side stream, beside the next step's gridding" if side else "in line, behind the step's gridding",
-                    "chosen_by": args.overlap, "measured_collective_ms": t_coll, "measured_gridding_ms": t_grid,
-                    "rule": "side when the collective alone takes more than 1/6 of a gridding step"}
-        if side and comm is None:
-            red = OverlappedGridReducer(bufs, rows=rows)
-        elif side:
-            red = OverlappedCommReducer(comm, bufs, rows=rows)
+
+        def make_reducer(side):
+            if side and comm is None:
+                return OverlappedGridReducer(bufs, rows=rows)
+            if side:
+                return OverlappedCommReducer(comm, bufs, rows=rows)
+            return InlineGridReducer(bufs, rows=rows, comm=comm)
+
+        def trial(side, res, yld, k=4):
+            ctx.set_option("reserve_cus", res)
+            ctx.set_option("yield_cus", yld)
+            r = make_reducer(side)
+            t_ = 0.0
+            for i in range(2 + k):
+                if i == 2:
+                    r.finish()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t_ = time.perf_counter()
+                g_ = r.begin(i)
+                if aw:
+                    ctx.convgrid4(gcf, akerns, g_, (u, v, None), (wb, a1, a2), vis)
+                else:
+                    ctx.convgrid2(gcf, g_, (u, v, None), wb, vis)
+                r.end(i)
+            r.finish()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_ = (time.perf_counter() - t_) / k * 1e3
+            r.close()
+            return t_
+
+        if args.overlap == "inline":
+            cands = [(False, 0, 0)]
+        elif args.reserve_cus >= 0 or args.yield_cus >= 0:
+            cands = [(True, max(args.reserve_cus, 0), max(args.yield_cus, 0))]
         else:
-            red = InlineGridReducer(bufs, rows=rows, comm=comm)
+            cands = [(True, 0, 0), (True, 0, 64), (True, 32, 0)]
+        if args.overlap == "auto":
+            cands.insert(0, (False, 0, 0))
+        trial(*cands[0], k=1)  # first use of everything: plans, RCCL's own warm-up
+        ms = torch.tensor([trial(*c_) for c_ in cands], dtype=torch.float64, device=device) if len(cands) > 1 else torch.zeros(1, dtype=torch.float64, device=device)
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        best = int(torch.argmin(ms).item())
+        side, reserve, yield_cus = cands[best]
+        names = [("side stream" if c_[0] else "in line") + (f", {c_[1]} CUs reserved" if c_[1] else "") +
+                 (f", {c_[2]} CUs yielding" if c_[2] else "") for c_ in cands]
+        schedule = {"collective_runs": "side stream, beside the next step's gridding" if side else "in line, behind the step's gridding",
+                    "chosen_by": "measurement" if len(cands) > 1 else "flags",
+                    "tried_ms_per_step": {nm: round(float(x), 4) for nm, x in zip(names, ms.tolist())} if len(cands) > 1 else None,
+                    "rule": "the fastest of the tried schedules (max over ranks of an untimed 4-step trial each)"}
+        red = make_reducer(side)
+        ctx.set_option("yield_cus", yield_cus)
         for b_ in bufs:
             b_.zero_()
-    if reserve:
-        ctx.set_option("reserve_cus", reserve)
+    ctx.set_option("reserve_cus", reserve)
     counter = [0]
 
     def step():
@@ -695,7 +728,7 @@ def main():
         ar_ms = e0.elapsed_time(e1) / 5
         nbytes = int(part.numel() * 16)
         multi = {"rccl_ranks": dist.get_world_size(), "collective": args.collective, "scaling": args.scaling,
-                 "reduced_rows": list(rows) if rows else [0, N], "reserve_cus": reserve, "schedule": schedule,
+                 "reduced_rows": list(rows) if rows else [0, N], "reserve_cus": reserve, "yield_cus": yield_cus, "schedule": schedule,
                  "allreduce_bytes": nbytes, "allreduce_ms_alone": ar_ms,
                  "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (ar_ms * 1e-3) / 1e9 if world > 1 else None,
                  "gridding_ms_per_step": float(np.mean(ker_ms) + np.mean(pre_ms)),
@@ -790,7 +823,7 @@ def main():
                 "name": args.workload,
                 "vis_per_gpu": n_rank, "vis_total": n_total, "scaling": args.scaling, "seed": args.seed, "grid": N, "w_planes": W, "support": S, "oversample": Q,
                 "parallelism": f"vis-sharded x{world}" + (f" + RCCL fp64 grid sum per step ({args.collective}; "
-                                                          f"{schedule['collective_runs']}; {reserve} CUs reserved)"
+                                                          f"{schedule['collective_runs']}; {reserve} CUs reserved, {yield_cus} yielding)"
                                                           if world > 1 else ""),
                 "scaling_note": ("weak: one global counter-based stream of n_gpus x vis_per_gpu visibilities, rank r grids "
                                  "[r, r + 1) x vis_per_gpu of it; value = vis_total / step time" if args.scaling == "weak" else

@@ -100,6 +100,13 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               remaining CU, so that a collective queued on another stream (RCCL's kernel, a copy) finds CUs to start
  *               on while the tile kernel runs instead of waiting ~10 ms for it to end; costs the tile kernel
  *               k / num_cu of its throughput (profiles/r03_reserve_cus.txt)
+ *   "yield_cus"  the cheaper way to the same end (0 = off; ignored while "reserve_cus" is set): k CUs' worth of the tile
+ *               kernel's work-groups are not persistent - each takes eight work items and leaves, and up to 2 048
+ *               further ones are launched to follow them - so a kernel queued on another stream gets a CU within a few
+ *               hundred microseconds while nothing idles when none is queued (+0.5 % on the tile kernel instead of
+ *               +10 %).  Use multiples of 32 (one CU per shader engine of every XCD): with fewer the dispatcher's
+ *               rotation over the shader engines stops at one without a free CU and the rest of the k stay idle
+ *               (profiles/r03_yield_cus.txt)
  *   "bigtile"   the tap-reusing kernel's tile uses all of the LDS (65 x 110 cells at 15 x 15 instead of 65 x 89): a
  *               quarter more visibilities per kernel slice and work item, for an address add per tap step; pays
  *               where items are sparse (fewer than two visibilities per slice and item), not where the LDS atomic
@@ -308,8 +315,10 @@ int gridhip_comm_get_option(gridhip_comm *comm, const char *key, int64_t *value)
 /* The hipStream_t device i's collectives are enqueued on.  Default: the context's own stream, i.e. ordered after its
  * gridding calls and before the next one.  A host that wants step i's all-reduce to run beside step i+1's gridding
  * passes a side stream here and orders the two itself (an event recorded after the gridding, waited for by the side
- * stream; python/gridhip/distributed.py: OverlappedCommReducer), together with the context option "reserve_cus" so
- * that the persistent tile kernel leaves the collective's kernel compute units to run on.
+ * stream; python/gridhip/distributed.py: OverlappedCommReducer).  A collective's kernel that becomes ready at the
+ * boundary between two steps takes its CUs as the tile kernel's work-groups retire; one that becomes ready in the middle
+ * of a persistent tile kernel (the all-gather after the reduce-scatter) waits for its end unless the context options
+ * "yield_cus" or "reserve_cus" make CUs come free.
  * gridhip_comm_convgrid2 (synchronous) always reduces on the gridding streams. */
 int gridhip_comm_set_stream(gridhip_comm *comm, int i, void *hip_stream);
 int gridhip_comm_reset_stream(gridhip_comm *comm, int i);

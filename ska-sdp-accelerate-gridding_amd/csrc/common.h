@@ -52,6 +52,8 @@ struct Geom {
     int32_t fgh, fgw, px, py, P;
     int32_t ob, kb;       // record layout: bits of the orig and kslice fields (set_rec_bits)
     int32_t dense;        // which table of walker weights (tile_sorted.hip): 1 = the steep one (make_geom)
+    int32_t npersist;     // tap-reusing kernel: work-groups [0, npersist) run until the queues are empty; the others
+    int32_t budget;       // take at most `budget` work items and leave (option "yield_cus", tile_sorted.hip)
     int32_t imoff;        // tap-reusing kernel: bytes from the re to the im plane of the LDS tile; 0 = the fixed 65528 that a DS
                           // instruction's offset field holds ("bigtile": a tile that uses all of the LDS, tile_sorted.hip)
     // division by Tx, Ty, W, P, px in the counting sweep without a divide: x / d == umulhi(x, m) >> s for 0 <= x < 2^31
@@ -111,7 +113,7 @@ __host__ __device__ __forceinline__ RecWord rec_pack(const Geom &g, int32_t lxy,
 }
 
 struct Options {
-    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0, rec_bits = 0, wtable = 0, reserve_cus = 0, subfoot = 0, bigtile = 0;
+    int64_t tile = 0, block = 0, chunk = 0, wgroups = 0, variant = 0, sort = 0, dbg = 0, prepass = 0, fault_inject = 0, aw_cache = 1, tile_x = 0, tile_y = 0, coarse_shift = 0, scatter_chunk = 0, count_unroll = 0, rec_bits = 0, wtable = 0, reserve_cus = 0, subfoot = 0, bigtile = 0, yield_cus = 0;
 };
 
 struct Workspace {

@@ -416,6 +416,7 @@ static int64_t *opt_slot(gridhip_ctx *ctx, const char *key)
     if (!strcmp(key, "reserve_cus")) return &ctx->opt.reserve_cus;
     if (!strcmp(key, "subfoot")) return &ctx->opt.subfoot;
     if (!strcmp(key, "bigtile")) return &ctx->opt.bigtile;
+    if (!strcmp(key, "yield_cus")) return &ctx->opt.yield_cus;
     return nullptr;
 }
 

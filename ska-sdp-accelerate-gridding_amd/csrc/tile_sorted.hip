@@ -158,10 +158,16 @@ __global__ void __launch_bounds__(1024, 4) tile_grid_sorted_kernel(Geom g, const
     // queue counter, then helps the other groups when its own queue is empty.
     int32_t *queue = scalars + 4;
     int turn = 0;  // sorter state: how many queues this work-group has seen empty
+    // Work-groups beyond the persistent ones (option "yield_cus") take a few work items and leave: the CUs they run on
+    // come free every few hundred microseconds, which is when a kernel queued on another stream - a collective - can
+    // take them; while nothing else is queued the next of these work-groups does.
+    int items_left = ((int)blockIdx.x >= g.npersist) ? g.budget : 0x7fffffff;
     auto prepare = [&](int slot) {
         WorkItem w;
         int grp = 0;
         bool have = false;
+        if (items_left <= 0) turn = g.ngroups;
+        --items_left;
         while (turn < g.ngroups) {
             grp = (blockIdx.x + turn) % g.ngroups;
             int item = 0;
@@ -728,9 +734,10 @@ bool sorted_plan(const gridhip_ctx *ctx, const Geom &g, int block, int *nkeys, i
     return true;
 }
 
-int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t lds_bytes, int nkeys, int batch,
+int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g_in, int block, size_t lds_bytes, int nkeys, int batch,
                             int64_t n, const double *gcf, const double *vis, double *grid, bool degrid)
 {
+    Geom g = g_in;
     Tables t = tables_of(ctx, g);
     const RecWord *recs = (const RecWord *)ctx->recs.ptr;
     if (g.chunk > batch) return fail(ctx, GRIDHIP_EINVAL, "sorted kernel: chunk %d exceeds its work-item capacity %d", g.chunk, batch);
@@ -747,6 +754,22 @@ int launch_tile_grid_sorted(gridhip_ctx *ctx, const Geom &g, int block, size_t l
     nblk = ctx->opt.reserve_cus ? (nblk / g.ngroups) * g.ngroups : ((nblk + g.ngroups - 1) / g.ngroups) * g.ngroups;
     const int most = work_blocks(g, n);
     if (nblk > most) nblk = most > g.ngroups ? (most / g.ngroups) * g.ngroups : g.ngroups;
+    g.npersist = nblk;
+    g.budget = 0;
+    // option "yield_cus" = k: k CUs' worth of the work-groups are not persistent - instead, up to 2048 further
+    // work-groups of 8 work items each are launched, which the dispatcher starts as CUs come free
+    if (ctx->opt.yield_cus > 0 && !ctx->opt.reserve_cus) {
+        int k = (int)ctx->opt.yield_cus * per_cu;
+        k = (k / g.ngroups) * g.ngroups;
+        if (k > 0 && nblk - k >= g.ngroups) {
+            g.npersist = nblk - k;
+            g.budget = 8;
+            int extra = most - g.npersist;
+            extra = extra > 2048 ? 2048 : extra;
+            extra = (extra / g.ngroups) * g.ngroups;
+            nblk = g.npersist + (extra > k ? extra : k);
+        }
+    }
     const dim3 gr(nblk), bl(block);
     // two sorted lists (current item, next item) per resident work-group: 8 B (meta, orig) per record, and for the aw
     // gridders, whose sorter stages the values, 16 B more

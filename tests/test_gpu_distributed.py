@@ -197,11 +197,16 @@ def test_bench_multi_gpu_branch_with_one_rank(collective):
     assert rec["n_gpus"] == 1 and rec["multi_gpu"]["rccl_ranks"] == 1 and rec["multi_gpu"]["collective"] == collective
     assert rec["multi_gpu"]["allreduce_ms_alone"] > 0 and rec["errors"] == 0
     assert rec["check"]["rel_err"] <= 1e-10 and rec["multi_gpu"]["check_rel_err"] == rec["check"]["rel_err"]
-    assert rec["multi_gpu"]["reduced_rows"] == [4096 // 2 - 15 // 2 - 1, 4096] and rec["multi_gpu"]["reserve_cus"] == 16
+    assert rec["multi_gpu"]["reduced_rows"] == [4096 // 2 - 15 // 2 - 1, 4096]
     assert rec["scaling"] == "weak" and rec["multi_gpu"]["scaling"] == "weak"
-    sch = rec["multi_gpu"]["schedule"]  # (one rank: the collective costs nothing, auto puts it in line)
-    assert sch["collective_runs"].startswith("in line" if collective == "cabi" else "side stream")
-    assert sch["measured_gridding_ms"] > 0 and sch["measured_collective_ms"] >= 0
+    sch = rec["multi_gpu"]["schedule"]
+    side = sch["collective_runs"].startswith("side stream")
+    assert rec["multi_gpu"]["reserve_cus"] == (16 if side else 0) and rec["multi_gpu"]["yield_cus"] == 0
+    if collective == "cabi":  # auto with the reservation given: in line against the side stream with 16 CUs idle, measured
+        assert sch["chosen_by"] == "measurement" and len(sch["tried_ms_per_step"]) == 2
+        assert min(sch["tried_ms_per_step"].values()) > 0
+    else:
+        assert side and sch["chosen_by"] == "flags"
     assert 0 < rec["roofline"]["frac"] <= 1 and 0 < rec["roofline"]["lds_floor_frac"] <= 1
     assert rec["roofline"]["bound"] == "lds_atomic" and 1.0 < rec["roofline"]["clock_GHz"] < 2.6
 
@@ -335,4 +340,8 @@ def test_bench_with_two_real_ranks_sharing_the_gpu(scaling, overlap):
     m = rec["multi_gpu"]
     assert m["rccl_ranks"] == 2 and m["reduced_rows"] == [2040, 4096] and m["allreduce_bytes"] == (4096 - 2040) * 4096 * 16
     assert m["schedule"]["collective_runs"].startswith("side" if overlap == "side" else "in line") or overlap == "auto"
-    assert m["reserve_cus"] == (32 if m["schedule"]["collective_runs"].startswith("side") else 0)
+    tried = m["schedule"]["tried_ms_per_step"]
+    assert m["schedule"]["chosen_by"] == ("flags" if overlap == "inline" else "measurement")
+    assert tried is None if overlap == "inline" else len(tried) == (3 if overlap == "side" else 4)
+    assert (m["reserve_cus"], m["yield_cus"]) in ((0, 0), (0, 64), (32, 0))
+    assert m["schedule"]["collective_runs"].startswith("side") or (m["reserve_cus"], m["yield_cus"]) == (0, 0)

@@ -816,6 +816,31 @@ def test_reserved_cus_do_not_change_the_grid(ctx, oracle):
         ctx.set_option("sort", 0)
 
 
+@pytest.mark.parametrize("S", [15, 23])
+def test_yielding_cus_do_not_change_the_grid(ctx, oracle, S):
+    """Option "yield_cus": part of the tile kernel's work-groups take eight work items and leave, further ones are
+    started in their place (so that a kernel queued on another stream gets CUs).  Every work item is still processed
+    exactly once: grid and degrid against the oracle for few, many and more-than-there-are CUs."""
+    N, n = 1024, 2_000_000
+    gcf, u, v, wb, vis = case(500 + S, N, N, 8, 4, S, S, n, spread=0.5)
+    ref = oracle.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), u, v, wb, vis, mt_mode=2)
+    rng = np.random.default_rng(S)
+    G = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    dref = oracle.degrid2(gcf, G, u, v, wb)
+    try:
+        for k in (32, 64, 248, 1000):
+            ctx.set_option("yield_cus", k)
+            ctx.set_option("sort", 1)
+            got = ctx.convgrid2(gcf, np.zeros((N, N), dtype=np.complex128), (u, v, None), wb, vis)
+            assert ctx.get_option("last_path") == 1 and ctx.get_option("errors") == 0
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-10
+            dg = ctx.degrid2(gcf, G, (u, v, None), wb)
+            assert np.abs(dg - dref).max() / np.abs(dref).max() < 1e-10
+    finally:
+        ctx.set_option("yield_cus", 0)
+        ctx.set_option("sort", 0)
+
+
 @pytest.mark.parametrize("S", [15, 21, 9])
 def test_bigtile_matches_oracle(ctx, oracle, S):
     """Option "bigtile": the tap-reusing kernel's tile uses all of the LDS, its im plane at a run-time distance from

@@ -12,7 +12,7 @@ constexpr int NREG = 24;  // double2 values a lane holds at once: ~110 VGPRs, mo
 // stamps[4 * b .. 4 * b + 3] (optional): work-group b's start and end on the 100 MHz real-time counter, its XCC_ID and
 // its HW_ID (which CU it ran on) - the probe counts how many work-groups started while the tile kernel was running
 __global__ void __launch_bounds__(256) fat_copy_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n,
-                                                       long long *__restrict__ stamps)
+                                                       long long *__restrict__ stamps, int reps)
 {
     __shared__ double pad[4096];  // 32 KB: more than a CU running the tile kernel has left
     if (threadIdx.x == 0) pad[blockIdx.x & 4095] = 0.0;
@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(256) fat_copy_kernel(const double2 *__restrict
         stamps[4 * blockIdx.x + 3] = (long long)hw;
     }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int rep = 0; rep < reps; ++rep)  // one launch that stays for as long as a collective's kernel does
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < n; base += stride * NREG) {
         double2 r[NREG];
 #pragma unroll
@@ -47,6 +48,14 @@ __global__ void __launch_bounds__(256) fat_copy_kernel(const double2 *__restrict
 extern "C" int fat_copy(void *dst, const void *src, int64_t n_double2, int blocks, void *stream, void *stamps)
 {
     hipLaunchKernelGGL(fat_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double2 *)src, (double2 *)dst,
-                       n_double2, (long long *)stamps);
+                       n_double2, (long long *)stamps, 1);
+    return (int)hipGetLastError();
+}
+
+// the same in ONE launch that copies `reps` times - a collective is one long-lived kernel, not a train of short ones
+extern "C" int fat_copy_rep(void *dst, const void *src, int64_t n_double2, int blocks, int reps, void *stream, void *stamps)
+{
+    hipLaunchKernelGGL(fat_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double2 *)src, (double2 *)dst,
+                       n_double2, (long long *)stamps, reps);
     return (int)hipGetLastError();
 }

@@ -9,7 +9,7 @@ work-groups retire, and the next tile kernel's persistent work-groups then start
 queues.  This probe runs that pipeline on one GPU with the stand-in of tools/micro/fat_copy.hip (64 work-groups, 197
 VGPRs + 32 KB LDS each) repeated `passes` times per step to last about as long as a collective would, and reports per
 (reserve_cus, passes): the step time against the pipeline without any side-stream work, and how long after its issue
-the stand-in finished.   usage: python tools/pipeline_overlap_probe.py [cfg3|cfg5]"""
+the stand-in finished.   usage: python tools/pipeline_overlap_probe.py [cfg3|cfg5] [reserve_cus|yield_cus] [one-launch]"""
 import ctypes
 import os
 import sys
@@ -36,6 +36,8 @@ dst = torch.empty_like(src)
 side = torch.cuda.Stream()
 fat = ctypes.CDLL(os.path.join(ROOT, "tools", "micro", "libfatcopy.so"))
 fat.fat_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+fat.fat_copy_rep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+ONE_LAUNCH = len(sys.argv) > 3 and sys.argv[3] == "one-launch"  # the stand-in as one long-lived kernel instead of `passes` launches
 ev = lambda: torch.cuda.Event(enable_timing=True)
 
 # how long one pass of the stand-in takes on an idle GPU
@@ -52,8 +54,10 @@ one = a.elapsed_time(b) / 10
 print(f"# {wl}: {n} vis, {N}^2 grid; stand-in: {src.numel() * 16 / 1e6:.0f} MB copied by 64 fat work-groups, {one:.3f} ms per pass on an idle GPU")
 print("reserve_cus  passes  stand_in_alone_ms  step_ms_no_side_work  step_ms_with_stand_in  stand_in_issue_to_done_ms  hidden")
 STEPS = 12
-for reserve in (0, 32):
-    ctx.set_option("reserve_cus", reserve)
+OPT = sys.argv[2] if len(sys.argv) > 2 else "reserve_cus"  # or "yield_cus"
+print(f"# option {OPT}; stand-in as {'one launch' if ONE_LAUNCH else 'a train of launches'}")
+for reserve in (0, 32) if OPT == "reserve_cus" else (32, 64):
+    ctx.set_option(OPT, reserve)
     for passes in (0, 8, 24, 60):
         done = [None, None]
         spans = []
@@ -73,8 +77,11 @@ for reserve in (0, 32):
                 side.wait_event(e)
                 s0, s1 = ev(), ev()
                 s0.record(side)
-                for _ in range(passes):
-                    fat.fat_copy(dst.data_ptr(), src.data_ptr(), src.numel(), 64, side.cuda_stream, None)
+                if ONE_LAUNCH:
+                    fat.fat_copy_rep(dst.data_ptr(), src.data_ptr(), src.numel(), 64, passes, side.cuda_stream, None)
+                else:
+                    for _ in range(passes):
+                        fat.fat_copy(dst.data_ptr(), src.data_ptr(), src.numel(), 64, side.cuda_stream, None)
                 s1.record(side)
                 done[i % 2] = (s0, s1)
                 spans.append((s0, s1))
@@ -88,4 +95,4 @@ for reserve in (0, 32):
             span = sorted(x.elapsed_time(y) for x, y in spans[2:])[len(spans[2:]) // 2]
             print(f"{reserve:11d}  {passes:6d}  {one * passes:17.3f}  {base:20.3f}  {step:21.3f}  {span:25.3f}  "
                   f"{'yes' if step < base + 0.5 * one * passes else 'no'}", flush=True)
-ctx.set_option("reserve_cus", 0)
+ctx.set_option(OPT, 0)

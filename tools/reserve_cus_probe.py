@@ -10,7 +10,7 @@ beside it, and when the copy finished relative to the pass's start - "copy_end <
 tile kernel instead of after it.  Two stand-ins: torch's copy kernel (few registers, no LDS: it fits into what the
 tile kernel leaves free on the CUs it occupies) and tools/micro/fat_copy.hip (~110 VGPRs per lane and 32 KB of LDS
 per work-group, as a collective's kernel has: it only fits on a CU the tile kernel does not occupy).
-usage: python tools/reserve_cus_probe.py [cfg3|cfg5]"""
+usage: python tools/reserve_cus_probe.py [cfg3|cfg5] [reserve_cus|yield_cus]"""
 import ctypes
 import os
 import sys
@@ -79,9 +79,10 @@ def copy_on_side(kind):
         assert rc == 0
 
 
-print("stand_in  reserve_cus  pass_alone_ms  pass_with_copy_ms  copy_start_ms  copy_end_ms  copy_ran_beside")
+print("stand_in  cus_given_up  pass_alone_ms  pass_with_copy_ms  copy_start_ms  copy_end_ms  copy_ran_beside")
+OPT = sys.argv[2] if len(sys.argv) > 2 else "reserve_cus"  # or "yield_cus"
 for kind, k in [(kind, k) for kind in (("torch", "fat") if fat else ("torch",)) for k in (0, 8, 16, 24, 32, 64)]:
-    ctx.set_option("reserve_cus", k)
+    ctx.set_option(OPT, k)
     ctx.enable_timing(True)
     for _ in range(2):
         step()
@@ -120,4 +121,4 @@ for kind, k in [(kind, k) for kind in (("torch", "fat") if fat else ("torch",)) 
                  f"{t0s.max().item():.2f} ms after the first; on {cus} distinct (XCC, CU)")
     print(f"{kind:8s}  {k:11d}  {med(alone):13.3f}  {med(both):17.3f}  {med(cbeg):13.3f}  {med(cend):11.3f}  {'yes' if med(cend) < med(both) - 0.5 else 'no'}" + extra,
           flush=True)
-ctx.set_option("reserve_cus", 0)
+ctx.set_option(OPT, 0)
