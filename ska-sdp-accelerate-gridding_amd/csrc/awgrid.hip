@@ -199,6 +199,47 @@ __global__ void aw_build_generic_kernel(int S, const double2 *__restrict__ wkern
     }
 }
 
+// The staged operands are native two-element vectors, not double2 structs: assigning a struct from global memory is a
+// memcpy into the array, and an array that is the target of memcpys and lives across the group loop is left in scratch
+// memory by the compiler (seen: 60 scratch stores and 30 scratch loads per group).
+typedef double aw_d2 __attribute__((ext_vector_type(2)));
+
+// Requests the operands of kernel id_ of a builder group into sa / sb: which S x S arrays it convolves is brought into
+// range before it becomes an address; all of the lane's loads together (a load-store loop would pay the memory latency
+// per trip).
+template <int S, bool PAIR, int NE>
+__device__ __forceinline__ void aw_request_operands(aw_d2 (&sa)[NE], aw_d2 (&sb)[NE], int64_t id_, int nk, int x,
+                                                    const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
+                                                    const unsigned long long *__restrict__ ukey,
+                                                    const int32_t *__restrict__ pairlist, int64_t A, int64_t npair,
+                                                    int64_t nslice, int32_t *__restrict__ errors)
+{
+    constexpr int S2 = S * S;
+    size_t ia = 0, ib = 0;
+    if (id_ < nk) {
+        int bad = 0;
+        if (PAIR) {
+            int64_t pq = pairlist[id_];
+            if (pq < 0 || pq >= A * A) {
+                pq = 0;
+                ++bad;
+            }
+            ia = (size_t)(pq / A);
+            ib = (size_t)(pq - (int64_t)ia * A);
+        } else
+            aw_key_operands(ukey[id_], npair, nslice, &ia, &ib, &bad);
+        if (bad && x == 0) atomicAdd(errors, bad);
+    }
+    const aw_d2 *pk = reinterpret_cast<const aw_d2 *>(pairk + ia * S2);
+    const aw_d2 *wk = reinterpret_cast<const aw_d2 *>(wkerns + ib * S2);
+#pragma unroll
+    for (int t = 0; t < NE; ++t) {
+        const int e = min(x + 16 * t, S2 - 1);
+        sa[t] = pk[e];
+        sb[t] = wk[e];
+    }
+}
+
 // Compile-time support, organised for the fp64 vector ALU.  A wave builds four kernels at a time: lane = (kernel q,
 // column x), and the lane keeps out[y][x] for all S rows y in registers.  The loop nest is ordered so that one LDS
 // read feeds many FMAs: for each column j of the pair kernel the lane fetches the S values a[i][j] (all i) and the
@@ -209,7 +250,8 @@ __global__ void aw_build_generic_kernel(int S, const double2 *__restrict__ wkern
 // PAIR: the same machine builds the antenna-pair products: entry s = convolve2d(akerns[p], akerns[q]) for
 // pairlist[s] = p * A + q (wkerns = pairk = akerns, not conjugated).
 // ABL (tuning builds, option "dbg"): 1 = the operands are read from LDS once per group instead of once per column j
-// (wrong results: what the loop costs without its LDS reads), 2 = no stores of the results
+// (wrong results: what the loop costs without its LDS reads), 2 = no stores of the results, 4 = the group's operands
+// requested at its start, not a group ahead (right results)
 template <int S, bool PAIR, int ABL = 0>
 __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict__ wkerns, const double2 *__restrict__ pairk,
                                                        const unsigned long long *__restrict__ ukey,
@@ -239,48 +281,32 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
         const int pos = e - C, col = pos >= 0 ? pos % PB : -1;
         if (pos < 0 || col >= S) bbuf[e] = make_double2(0.0, 0.0);
     }
-    const int64_t groups = ((int64_t)nk + 3) / 4;
-    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t groups = ((int64_t)nk + 3) / 4, stride = (int64_t)gridDim.x * 4;
+    constexpr int NE = (S2 + 15) / 16;
+    constexpr bool AHEAD = !(ABL & 4);  // the next group's operands are requested before the current group's products
+    aw_d2 sa[NE], sb[NE];
+    const int64_t npair = PAIR ? 0 : min((int64_t)counters[0], npair_cap);
+#define GH_REQUEST(g_) aw_request_operands<S, PAIR, NE>(sa, sb, (g_) * 4 + q, nk, x, wkerns, pairk, ukey, pairlist, A, npair, nslice, errors)
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    if (AHEAD && grp < groups) GH_REQUEST(grp);
+    for (; grp < groups; grp += stride) {
         const int64_t id = grp * 4 + q;
         const bool have = id < nk;
-        size_t ia = 0, ib = 0;  // which S x S arrays are convolved (brought into range before they become addresses)
-        if (have) {
-            int bad = 0;
-            if (PAIR) {
-                int64_t pq = pairlist[id];
-                if (pq < 0 || pq >= A * A) {
-                    pq = 0;
-                    ++bad;
-                }
-                ia = (size_t)(pq / A);
-                ib = (size_t)(pq - (int64_t)ia * A);
-            } else
-                aw_key_operands(ukey[id], min((int64_t)counters[0], npair_cap), nslice, &ia, &ib, &bad);
-            if (bad && x == 0) atomicAdd(errors, bad);
-        }
-        const double2 *pk = pairk + ia * S2;
-        const double2 *wk = wkerns + ib * S2;
+        if (!AHEAD) GH_REQUEST(grp);
         __builtin_amdgcn_wave_barrier();  // (the previous group's reads of this LDS region are done: same wave)
-        {   // all of the lane's loads first, then its LDS stores (a load-store loop would pay the memory latency per trip)
-            constexpr int NE = (S2 + 15) / 16;
-            double2 sa[NE], sb[NE];
 #pragma unroll
-            for (int t = 0; t < NE; ++t) {
-                const int e = min(x + 16 * t, S2 - 1);
-                sa[t] = pk[e];
-                sb[t] = wk[e];
-            }
-#pragma unroll
-            for (int t = 0; t < NE; ++t) {
-                const int e = x + 16 * t;
-                if (e < S2) {
-                    abuf[e] = sa[t];
-                    bbuf[C + (e / S) * PB + (e % S)] = sb[t];
-                }
+        for (int t = 0; t < NE; ++t) {
+            const int e = x + 16 * t;
+            if (e < S2) {
+                *reinterpret_cast<aw_d2 *>(abuf + e) = sa[t];
+                *reinterpret_cast<aw_d2 *>(bbuf + C + (e / S) * PB + (e % S)) = sb[t];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // With one wave per SIMD nothing else covers the ~2 us of these loads: they are in flight during the products
+        // (120 registers at 15 x 15, which the one wave has: 512 per lane).
+        if (AHEAD) GH_REQUEST(grp + stride);  // (past the last group: kernel 0's operands, not used)
 
         double2 acc[S];
 #pragma unroll
@@ -325,6 +351,7 @@ __global__ void __launch_bounds__(256) aw_build_kernel(const double2 *__restrict
         stamp[2] = (long long)__builtin_amdgcn_s_memtime();
         stamp[3] = (long long)__builtin_amdgcn_s_memrealtime();
     }
+#undef GH_REQUEST
 }
 
 // records come out of the binning pre-pass with kslice = the visibility's index: replace it by its kernel's
@@ -370,14 +397,14 @@ int launch_build(gridhip_ctx *ctx, const double2 *wk, const double2 *pairk, cons
     constexpr int C = S / 2, PB = S + C, BSZ = C + S * PB;
     const size_t lds = (size_t)16 * (S * S + BSZ) * sizeof(double2);
 #ifdef GRIDHIP_TUNING
-    if (S == 15 && !PAIR && ctx->opt.dbg >= 1 && ctx->opt.dbg <= 3) {  // ablations of the key builder (wrong results)
+    if (S == 15 && !PAIR && ctx->opt.dbg >= 1 && ctx->opt.dbg <= 4) {  // ablations of the key builder (1 - 3: wrong results)
 #define AW_ABL1(A_)                                                                                                         \
     if (ctx->opt.dbg == A_) {                                                                                               \
         GH_CHECK(raise_lds(ctx, aw_build_kernel<15, false, A_>));                                                           \
         hipLaunchKernelGGL((aw_build_kernel<15, false, A_>), dim3(ctx->num_cu), dim3(256), lds, ctx->stream, wk, pairk, ukey, \
                            pairlist, A, counters, which, fixed, cap, table, npair_cap, nslice, ctx->d_scalars + 31);       \
     }
-        AW_ABL1(1) AW_ABL1(2) AW_ABL1(3)
+        AW_ABL1(1) AW_ABL1(2) AW_ABL1(3) AW_ABL1(4)
 #undef AW_ABL1
         return GRIDHIP_OK;
     }
