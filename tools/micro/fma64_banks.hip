@@ -43,6 +43,14 @@ __global__ void __launch_bounds__(256) k(double *out, long long *cyc)
         if (MODE == 4)
             asm volatile(F(0, 32, 38) F(4, 32, 38) F(8, 32, 38) F(12, 32, 38) F(16, 32, 38) F(20, 32, 38) F(24, 32, 38) F(28, 32, 38)
                          F(0, 32, 38) F(4, 32, 38) F(8, 32, 38) F(12, 32, 38) F(16, 32, 38) F(20, 32, 38) F(24, 32, 38) F(28, 32, 38) ::: "memory");
+#define G(d, a, b) "v_fmac_f64 v[" #d ":" #d "+1], v[" #a ":" #a "+1], v[" #b ":" #b "+1]\n"
+#define H(d, a, b, n) "v_fmac_f64_dpp v[" #d ":" #d "+1], v[" #a ":" #a "+1], v[" #b ":" #b "+1] row_newbcast:" #n " row_mask:0xf bank_mask:0xf\n"
+        if (MODE == 5)  // the VOP2 form the compiler emits for most of the builder's products
+            asm volatile(G(0, 32, 36) G(2, 32, 36) G(4, 32, 36) G(6, 32, 36) G(8, 32, 36) G(10, 32, 36) G(12, 32, 36) G(14, 32, 36)
+                         G(16, 32, 36) G(18, 32, 36) G(20, 32, 36) G(22, 32, 36) G(24, 32, 36) G(26, 32, 36) G(28, 32, 36) G(30, 32, 36) ::: "memory");
+        if (MODE == 6)  // the same with the first factor taken from lane n of each row of 16 (DP ALU DPP: row_newbcast only)
+            asm volatile(H(0, 32, 36, 0) H(2, 32, 36, 1) H(4, 32, 36, 2) H(6, 32, 36, 3) H(8, 32, 36, 4) H(10, 32, 36, 5) H(12, 32, 36, 6) H(14, 32, 36, 7)
+                         H(16, 32, 36, 8) H(18, 32, 36, 9) H(20, 32, 36, 10) H(22, 32, 36, 11) H(24, 32, 36, 12) H(26, 32, 36, 13) H(28, 32, 36, 14) H(30, 32, 36, 15) ::: "memory");
     }
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1));
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
@@ -54,8 +62,9 @@ int main()
     long long *cyc;
     CK(hipMalloc(&cyc, 8));
     const char *names[] = {"A 0 mod 4, B 0 mod 4, acc alternating 0 / 2", "A 0, B 2, acc alternating", "A 2, B 2, acc alternating",
-                           "A 0, B 0, acc 0 (double2 .x * .x -> .x)", "A 0, B 2, acc 0"};
-    for (int m = 0; m < 5; ++m) {
+                           "A 0, B 0, acc 0 (double2 .x * .x -> .x)", "A 0, B 2, acc 0",
+                           "v_fmac_f64 (VOP2), operands as mode 0", "v_fmac_f64_dpp row_newbcast:n, operands as mode 0"};
+    for (int m = 0; m < 7; ++m) {
         for (int rep = 0; rep < 2; ++rep) {
             switch (m) {
                 case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, nullptr, cyc); break;
@@ -63,12 +72,14 @@ int main()
                 case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, nullptr, cyc); break;
                 case 3: hipLaunchKernelGGL(k<3>, dim3(256), dim3(256), 0, 0, nullptr, cyc); break;
                 case 4: hipLaunchKernelGGL(k<4>, dim3(256), dim3(256), 0, 0, nullptr, cyc); break;
+                case 5: hipLaunchKernelGGL(k<5>, dim3(256), dim3(256), 0, 0, nullptr, cyc); break;
+                case 6: hipLaunchKernelGGL(k<6>, dim3(256), dim3(256), 0, 0, nullptr, cyc); break;
             }
             CK(hipDeviceSynchronize());
         }
         long long h = 0;
         CK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
-        printf("mode %d  %-46s  %.3f cycles per v_fma_f64 (one wave per SIMD, 256 work-groups)\n", m, names[m], (double)h / (ITERS * 16.0));
+        printf("mode %d  %-46s  %.3f cycles per instruction (one wave per SIMD, 256 work-groups)\n", m, names[m], (double)h / (ITERS * 16.0));
     }
     return 0;
 }
