@@ -18,7 +18,7 @@ done
 python bench.py --dist core --no-cpu > $OUT/bench_cfg3_core.json 2> $OUT/bench_cfg3_core.err; echo "bench core rc=$?"
 # single-GPU pieces of the multi-GPU prediction: the step with 32 CUs reserved, at each GPU count's share of the stream
 for NV in 100000000 50000000 25000000 12500000; do
-  python tools/sweep.py --nvis $NV --reps 3 "" "reserve_cus=32" 2>&1 | grep -v amdgpu.ids | sed "s/^/cfg3 nvis=$NV  /" | tee -a $OUT/multigpu_pieces.txt
+  python tools/sweep.py --nvis $NV --reps 3 "" "yield_cus=64" "reserve_cus=32" 2>&1 | grep -v amdgpu.ids | sed "s/^/cfg3 nvis=$NV  /" | tee -a $OUT/multigpu_pieces.txt
 done
-python tools/sweep.py --workload cfg5 --reps 3 "" "reserve_cus=32" 2>&1 | grep -v amdgpu.ids | sed "s/^/cfg5  /" | tee -a $OUT/multigpu_pieces.txt
+python tools/sweep.py --workload cfg5 --reps 3 "" "yield_cus=64" "reserve_cus=32" 2>&1 | grep -v amdgpu.ids | sed "s/^/cfg5  /" | tee -a $OUT/multigpu_pieces.txt
 python tools/measure_all.py cfg2 core degrid plan host > $OUT/secondary.jsonl 2>&1; echo "secondary rc=$?"
