@@ -39,7 +39,7 @@ gcf = bench.synth_kernels(W, Q, S, dev)
 u, v, wb, vis = bench.synth_vis(n, N, W, S, 0x5EEDC0DE, dev, dist=a.dist)
 G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
 ctx.enable_timing(True)
-keys = ("tile", "tile_x", "tile_y", "block", "chunk", "wgroups", "variant", "sort", "dbg", "prepass", "coarse_shift", "scatter_chunk", "count_unroll", "wtable", "bigtile", "subfoot", "reserve_cus")
+keys = ("tile", "tile_x", "tile_y", "block", "chunk", "wgroups", "variant", "sort", "dbg", "prepass", "coarse_shift", "scatter_chunk", "count_unroll", "wtable", "bigtile", "subfoot", "reserve_cus", "yield_cus")
 for s in a.sets or [""]:
     for k in keys:
         try:
