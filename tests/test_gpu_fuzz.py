@@ -54,6 +54,7 @@ def make_case(seed, large=False):
         opts["reserve_cus"] = int(rng.choice([0, 8, 32, 200]))
         if "tile" in opts and rng.random() < 0.5:
             del opts["tile"]  # (bigtile only applies to automatically chosen tiles)
+    opts["yield_cus"] = int(rng.choice([0, 0, 32, 64, 250]))  # (ignored while reserve_cus is set)
     return (H, Wd, gcf, u, v, wb, vis, opts)
 
 
@@ -62,7 +63,7 @@ def test_fuzz_convgrid2_and_degrid2(ctx, oracle, seed):
     large = isinstance(seed, str)
     seed = 500 + int(seed[1:]) if large else seed
     H, Wd, gcf, u, v, wb, vis, opts = make_case(seed, large)
-    keys = ("tile", "block", "wgroups", "chunk", "sort", "prepass", "bigtile", "subfoot", "reserve_cus")
+    keys = ("tile", "block", "wgroups", "chunk", "sort", "prepass", "bigtile", "subfoot", "reserve_cus", "yield_cus")
     G0 = np.zeros((H, Wd), dtype=np.complex128)
     ref = oracle.convgrid2(gcf, G0.copy(), u, v, wb, vis)
     rng = np.random.default_rng(seed)

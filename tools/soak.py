@@ -43,7 +43,7 @@ scale = (vis.abs() * gcf.abs().sum(dim=(3, 4))[wb, yf, xf]).sum().item()
 del ks
 G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
 out = torch.empty(n, dtype=torch.complex128, device=dev)
-sets = [{}, {"wgroups": 4}, {"chunk": 4096}, {"prepass": 6}, {"tile": 64}, {"wtable": 1}, {"bigtile": 1}, {"reserve_cus": 32},
+sets = [{}, {"wgroups": 4}, {"chunk": 4096}, {"prepass": 6}, {"tile": 64}, {"wtable": 1}, {"bigtile": 1}, {"reserve_cus": 32}, {"yield_cus": 64},
         {"bigtile": 1, "wgroups": 4}]
 worst, t0 = 0.0, time.time()
 dref = None
