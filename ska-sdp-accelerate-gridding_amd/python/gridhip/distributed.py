@@ -91,10 +91,10 @@ class OverlappedGridReducer:
 class InlineGridReducer:
     """The same begin(i) / end(i) / finish() protocol without overlap: step i's collective is enqueued right behind its
     gridding, on the gridding stream (libgridhip's communicator) or with the gridding stream waiting for it
-    (torch.distributed), and the next step starts when it is done.  What a SHORT collective wants: beside a persistent
-    tile kernel that occupies every CU a side-stream collective does not start before that kernel ends unless CUs are
-    reserved for it (tools/pipeline_overlap_probe.py), and reserving them costs the gridding 10 %; a collective that
-    takes less than that is cheapest in line."""
+    (torch.distributed), and the next step starts when it is done.  What a SHORT collective may want: a collective on a
+    side stream shares the CUs and the memory system with the next step's gridding for as long as it runs
+    (tools/pipeline_overlap_probe.py); bench.py --overlap auto tries this schedule against the side-stream ones and
+    keeps the fastest."""
 
     def __init__(self, grids, group=None, rows=None, comm=None):
         self.grids, self.group, self.rows, self.c = grids, group, rows, comm
