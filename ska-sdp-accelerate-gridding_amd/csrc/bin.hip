@@ -375,6 +375,9 @@ __device__ __forceinline__ int block_exclusive_scan(int sum, int32_t *wtot, int 
     return base;
 }
 
+// Work-group 0: bin_start over all bins (and the cursors cleared); work-group 1 + grp: that w-group's work_start.  The
+// parts are independent, so they run side by side, each thread taking EPT consecutive counts per trip (a single
+// work-group doing one after the other with four counts per thread took 0.115 ms for the 110 000 bins of an 8192^2 grid).
 template <int NT>
 __global__ void __launch_bounds__(NT) bin_scan_kernel(Geom g, const int32_t *__restrict__ bin_count,
                                                         int32_t *__restrict__ bin_start,
@@ -382,50 +385,37 @@ __global__ void __launch_bounds__(NT) bin_scan_kernel(Geom g, const int32_t *__r
                                                         int32_t *__restrict__ cursor)
 {
     __shared__ int32_t wtot[16];
+    constexpr int EPT = 16;
     const int tid = threadIdx.x;
-    // ---- bin_start over all bins
-    {
-        int carry = 0;
-        for (int base = 0; base < g.nbins; base += 4 * NT) {
-            const int i0 = base + tid * 4;
-            int c[4];
+    const bool starts = blockIdx.x == 0;  // (uniform per work-group)
+    const int grp = (int)blockIdx.x - 1;
+    if (!starts && grp >= g.ngroups) return;
+    const int len = starts ? g.nbins : g.ntiles;
+    const int32_t *cnt = starts ? bin_count : bin_count + (size_t)grp * g.ntiles;
+    int32_t *dst = starts ? bin_start : work_start + (size_t)grp * (g.ntiles + 1);
+    int carry = 0;
+    for (int base = 0; base < len; base += EPT * NT) {
+        const int i0 = base + tid * EPT;
+        int c[EPT], sum = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = i0 + q < g.nbins ? bin_count[i0 + q] : 0;
-            int total;
-            int acc = carry + block_exclusive_scan<NT>(c[0] + c[1] + c[2] + c[3], wtot, &total);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (i0 + q < g.nbins) {
-                    bin_start[i0 + q] = acc;
-                    cursor[i0 + q] = 0;
-                }
-                acc += c[q];
-            }
-            carry += total;
+        for (int q = 0; q < EPT; ++q) {
+            c[q] = i0 + q < len ? cnt[i0 + q] : 0;
+            if (!starts) c[q] = (c[q] + g.chunk - 1) / g.chunk;  // work items of the tile: chunks of <= chunk visibilities
+            sum += c[q];
         }
-        if (tid == 0) bin_start[g.nbins] = carry;
-    }
-    // ---- work_start per group
-    for (int grp = 0; grp < g.ngroups; ++grp) {
-        const int32_t *cnt = bin_count + (size_t)grp * g.ntiles;
-        int32_t *ws = work_start + (size_t)grp * (g.ntiles + 1);
-        int carry = 0;
-        for (int base = 0; base < g.ntiles; base += 4 * NT) {
-            const int i0 = base + tid * 4;
-            int c[4];
+        int total;
+        int acc = carry + block_exclusive_scan<NT>(sum, wtot, &total);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = i0 + q < g.ntiles ? (cnt[i0 + q] + g.chunk - 1) / g.chunk : 0;
-            int total;
-            int acc = carry + block_exclusive_scan<NT>(c[0] + c[1] + c[2] + c[3], wtot, &total);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (i0 + q < g.ntiles) ws[i0 + q] = acc;
-                acc += c[q];
+        for (int q = 0; q < EPT; ++q) {
+            if (i0 + q < len) {
+                dst[i0 + q] = acc;
+                if (starts) cursor[i0 + q] = 0;
             }
-            carry += total;
+            acc += c[q];
         }
-        if (tid == 0) ws[g.ntiles] = carry;
+        carry += total;
     }
+    if (tid == 0) dst[len] = carry;
 }
 
 // One-level scatter (small streams).  `cap` = record slots the array holds: a slot outside it is never written
@@ -963,7 +953,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
                                    uv_stride, wbin, t.bin_count, (int32_t *)nullptr, t.scalars, b_lo, b_hi,
                                    PreFmt{wdw == 0 ? bb : -bb}, pre, zero_out);
         }
-        hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
+        hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1 + g.ngroups), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                            t.work_start, t.cursor);
         const PreFmt pf{bb};
 #define GH_TWO(P_, T_)                                                                                                  \
@@ -1003,7 +993,7 @@ int launch_bin(gridhip_ctx *ctx, const Geom &g, int64_t n, const double *u, cons
                            uv_stride, wbin, t.bin_count, block_hist, t.scalars, 0, g.nbins, PreFmt{0},
                            (unsigned long long *)nullptr, zero_out);
     }
-    hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
+    hipLaunchKernelGGL(bin_scan_kernel<1024>, dim3(1 + g.ngroups), dim3(1024), 0, ctx->stream, g, t.bin_count, t.bin_start,
                        t.work_start, t.cursor);
     if (lds_hist) {
         hipLaunchKernelGGL(bin_offsets_kernel, dim3((g.nbins + 255) / 256), dim3(256), 0, ctx->stream, g.nbins, blocks,
