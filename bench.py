@@ -572,7 +572,7 @@ def main():
                 return OverlappedCommReducer(comm, bufs, rows=rows)
             return InlineGridReducer(bufs, rows=rows, comm=comm)
 
-        def trial(side, res, yld, k=4):
+        def trial(side, res, yld, k=6):
             ctx.set_option("reserve_cus", res)
             ctx.set_option("yield_cus", yld)
             r = make_reducer(side)
@@ -614,7 +614,7 @@ def main():
         schedule = {"collective_runs": "side stream, beside the next step's gridding" if side else "in line, behind the step's gridding",
                     "chosen_by": "measurement" if len(cands) > 1 else "flags",
                     "tried_ms_per_step": {nm: round(float(x), 4) for nm, x in zip(names, ms.tolist())} if len(cands) > 1 else None,
-                    "rule": "the fastest of the tried schedules (max over ranks of an untimed 4-step trial each)"}
+                    "rule": "the fastest of the tried schedules (max over ranks of an untimed 6-step trial each)"}
         red = make_reducer(side)
         ctx.set_option("yield_cus", yield_cus)
         for b_ in bufs:
