@@ -46,15 +46,34 @@ __global__ void aw_pairs_kernel(int64_t n, int64_t A, const int64_t *__restrict_
                                 int32_t *__restrict__ slot, int32_t *__restrict__ pairlist, int32_t *__restrict__ counters,
                                 int32_t cap)
 {
+    const int lane = threadIdx.x & 63;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = a1[k], q = a2[k];
-        if (p < 0 || p >= A || q < 0 || q >= A) continue;
-        int32_t *s = slot + p * A + q;
-        if (*s != -1) continue;                    // (claimed already; a stale -1 only costs the atomic below)
-        if (atomicCAS(s, -1, -2) != -1) continue;  // somebody else claims it
-        const int32_t id = atomicAdd(&counters[0], 1);
-        if (id < cap) pairlist[id] = (int32_t)(p * A + q);
-        __hip_atomic_store(s, id < cap ? id : -3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int32_t *s = nullptr;
+        bool won = false;
+        const bool valid = p >= 0 && p < A && q >= 0 && q < A;
+        // consecutive samples of a baseline sit in neighbouring lanes: only the first lane of such a run tries the claim
+        const int64_t pq = valid ? p * A + q : -1;
+        const int64_t prev = __shfl_up(pq, 1);
+        if (valid && (lane == 0 || prev != pq)) {
+            s = slot + pq;
+            // (claimed already: nothing to do; a stale -1 only costs the atomic)
+            if (*s == -1) won = atomicCAS(s, -1, -2) == -1;
+        }
+        // the wave's new pairs are numbered together: one atomic on the counter per wave, not per pair (10^5 atomics
+        // on one address were most of this kernel's 0.19 ms)
+        const unsigned long long m = __ballot(won);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&counters[0], __popcll(m));
+            base = __shfl(base, leader);
+            if (won) {
+                const int32_t id = base + __popcll(m & ((1ull << lane) - 1));
+                if (id < cap) pairlist[id] = (int32_t)(p * A + q);
+                __hip_atomic_store(s, id < cap ? id : -3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -96,6 +115,7 @@ __global__ void aw_keys_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int3
                                int32_t *__restrict__ kid, int64_t *__restrict__ ok, unsigned long long *__restrict__ ukey,
                                int32_t *__restrict__ counters, int32_t cap)
 {
+    const int lane = threadIdx.x & 63;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t wb = wbin[k], p = a1[k], q = a2[k];
         const double pu = u[k * stride], pv = v[k * stride];
@@ -104,33 +124,63 @@ __global__ void aw_keys_kernel(int64_t H, int64_t Wd, int64_t n, int64_t W, int3
         // the reference would index out of range; such a visibility contributes nothing and is counted
         const bool bad = wb < 0 || wb >= W || ps < 0 || !(pu == pu) || !(pv == pv);
         int32_t id = -1;
+        bool won = false;
+        uint32_t hwon = 0;
+        unsigned long long kwon = 0;
+        unsigned long long key = AW_EMPTY;
         if (!bad) {
             int64_t x, y;
             int32_t xf, yf;
             frac_coord_dev(Wd, Q, pu, &x, &xf);
             frac_coord_dev(H, Q, pv, &y, &yf);
-            const unsigned long long key = ((unsigned long long)ps << 30) | (unsigned long long)((wb * Q + yf) * Q + xf);
+            key = ((unsigned long long)ps << 30) | (unsigned long long)((wb * Q + yf) * Q + xf);
             if (!cache) {
                 id = (int32_t)k;
                 ukey[k] = key;
-            } else {
-                uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & hmask;
+            }
+        }
+        if (cache) {
+            // consecutive samples of a baseline mostly share their key and sit in neighbouring lanes: only the first lane
+            // of such a run probes the table, the others take its slot (the atomics of this kernel are what it costs)
+            const unsigned long long prevkey = __shfl_up(key, 1);
+            const bool first = !bad && (lane == 0 || prevkey != key);
+            uint32_t h = 0;
+            if (first) {
+                h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & hmask;
                 for (;;) {
                     const unsigned long long cur = __hip_atomic_load(&htab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cur == key) break;
                     if (cur == AW_EMPTY) {
                         const unsigned long long old = atomicCAS(&htab[h], AW_EMPTY, key);
-                        if (old == AW_EMPTY) {  // ours: number it
-                            const int32_t nid = atomicAdd(&counters[1], 1);
-                            if (nid < cap) ukey[nid] = key;
-                            __hip_atomic_store(&hid[h], nid < cap ? nid : -3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old == AW_EMPTY) {  // ours: numbered below, together with the wave's other new keys
+                            won = true;
                             break;
                         }
                         if (old == key) break;
                     }
                     h = (h + 1) & hmask;  // (the table has at least twice as many slots as there are keys)
                 }
-                id = -(int32_t)h - 16;  // resolved by aw_kid_kernel once every number has been handed out
+                hwon = h;
+                kwon = key;
+            }
+            // the run's first lane: the highest lane at or below this one that probed
+            const unsigned long long fm = __ballot(first) & ((2ull << lane) - 1);
+            const int src = fm ? 63 - __clzll((long long)fm) : lane;
+            const uint32_t hrun = (uint32_t)__shfl((int)h, src);
+            if (!bad) id = -(int32_t)hrun - 16;  // resolved by aw_kid_kernel once every number has been handed out
+        }
+        // one atomic on the counter per wave for all of its new keys (3 x 10^5 atomics on one address were most of this
+        // kernel's 0.33 ms); nobody waits for hid[] inside this launch
+        const unsigned long long m = __ballot(won);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&counters[1], __popcll(m));
+            base = __shfl(base, leader);
+            if (won) {
+                const int32_t nid = base + __popcll(m & ((1ull << lane) - 1));
+                if (nid < cap) ukey[nid] = kwon;
+                __hip_atomic_store(&hid[hwon], nid < cap ? nid : -3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (bad && !cache) ukey[k] = 0;  // (every table entry is built: give the dropped one's a key that exists)
