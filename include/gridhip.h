@@ -120,7 +120,9 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               100 + t: widen the record's kernel-slice field until its fields take t <= 64 bits
  *   ("dbg", the ablation / profiling switch of tuning runs, exists only in the tuning build of the library,
  *   `make -C csrc tuning` -> lib/libgridhip_tuning.so; the shipped library rejects the key)
- * Read-only (gridhip_get_option): "last_path" = which gridder the last convgrid / convgrid2 / degrid2 / plan call used:
+ * Read-only (gridhip_get_option): "last_wgroups", "last_tile_x", "last_tile_y", "last_bigtile" = the geometry the last
+ * convgrid / convgrid2 / degrid2 call chose (w-groups, the LDS tile's interior, whether the tile uses all of the LDS);
+ * "last_path" = which gridder the last convgrid / convgrid2 / degrid2 / plan call used:
  * 1 = the tap-reusing tile kernel (square supports 5..32 with enough visibilities per work item), 2 = the same through
  * sub-footprints (other shapes: one record per spatial part of the kernel), 3 = the general tile kernel (small
  * problems, and the sizes listed under "Limits" below: 2 - 3 x slower per visibility at scale), 4 = direct

@@ -151,6 +151,10 @@ int prepare(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_t Q, int64
 int tile_kernels(gridhip_ctx *ctx, const Prep &p, const double *gcf, const double **out)
 {
     ctx->last_path = p.direct ? 4 : !p.sorted ? 3 : p.g.P > 1 || p.g.fgh != p.g.gh || p.g.fgw != p.g.gw ? 2 : 1;
+    ctx->last_geom[0] = p.g.ngroups;
+    ctx->last_geom[1] = p.g.Tx;
+    ctx->last_geom[2] = p.g.Ty;
+    ctx->last_geom[3] = p.g.imoff > 0;
     *out = gcf;
     if (p.g.P == 1 && p.g.fgh == p.g.gh && p.g.fgw == p.g.gw) return GRIDHIP_OK;
     const int64_t nsl = (int64_t)p.g.W * p.g.Q * p.g.Q;

@@ -168,6 +168,8 @@ struct gridhip_ctx {
     // 3 = general tile kernel (small problems; shapes or sizes the tap-reusing kernel does not take),
     // 4 = direct global-atomic scatter (option variant = 1, supports too large for an LDS tile)
     int last_path = 0;
+    // the geometry that call ran with (read-only options "last_wgroups", "last_tile_x", "last_tile_y", "last_bigtile")
+    int last_geom[4] = {0, 0, 0, 0};
 };
 
 namespace gridhip {

@@ -133,9 +133,20 @@ static int make_geom1(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_
     // distinct kernel slice = n / (tiles W Q^2)) and the halo's share shrinks.  The row pitch comes in steps of
     // 32 cells (bank-conflict rule, lds_pitch), so the candidates are the widest tile of each pitch with the
     // tallest height that fits: 65 x 89 for a 15 x 15 kernel, against 64 x 64 as a square power of two.
+    // how many w-groups a call gets when option "wgroups" does not say (see below, where it is applied): by the work
+    // per tile in visibilities of 15 x 15 taps
+    auto tiles_of = [&](int tx, int ty) {
+        const int ox = (((int)gw - 1 + tx - 1) / tx) * tx, oy = (((int)gh - 1 + ty - 1) / ty) * ty;
+        return (int64_t)((Wd - 1 + ox) / tx + 1) * (int64_t)((H - 1 + oy) / ty + 1);
+    };
+    auto auto_groups = [&](int64_t ntiles) {
+        const double work = (double)n / (double)ntiles * ((double)gh * (double)gw / 225.0);
+        return W < 8 ? 1 : work >= 8000.0 ? 8 : work >= 1200.0 ? 4 : work >= 600.0 ? 2 : 1;
+    };
+    // the sort's histogram: one counter per slice of a w-group - sized for 8 groups (or what option "wgroups" says) in
+    // the classic tile, whose 24 KB of room hold fewer groups' too; for the groups the call will get in the big tile
+    int64_t ng_est = ctx->opt.wgroups ? ctx->opt.wgroups : (W >= 8 ? 8 : 1);
     auto largest_tile = [&](bool big, int *otx, int *oty) {
-        // the sort's histogram: one counter per slice of a w-group (8 groups, or what option "wgroups" says)
-        const int64_t ng_est = ctx->opt.wgroups ? ctx->opt.wgroups : (W >= 8 ? 8 : 1);
         const size_t hist_need = (size_t)(((W + ng_est - 1) / ng_est + 2) * Q * Q * (parts > 0 ? parts : 1)) * 4 + 1024;
         const size_t hist_room = big ? hist_need : (hist_need > 24576 && hist_need < 65536 * 4 ? hist_need : 24576);
         const size_t plane_cap = big ? lds_cap : 65528;
@@ -167,6 +178,7 @@ static int make_geom1(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_
             const int64_t tiles = ((H + Ty - 1) / Ty) * ((Wd + Tx - 1) / Tx);
             const bool sparse = n >= ((int64_t)1 << 22) && n < 2 * tiles * W * Q * Q;
             int bx = 0, by = 0;
+            if (!ctx->opt.wgroups) ng_est = auto_groups(tiles_of(Tx, Ty));  // (the big tile has fewer tiles: at least as many groups, a histogram no larger)
             if ((ctx->opt.bigtile == 1 || sparse) && largest_tile(true, &bx, &by) > best) {
                 best = (size_t)bx * by;
                 Tx = bx;
@@ -207,10 +219,13 @@ static int make_geom1(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t W, int64_
     // w-plane groups: work items of group g run on XCD g (blockIdx round-robin), so that XCD's
     // 4 MiB L2 only has to hold W/8 planes of the kernel table instead of all of them (measured:
     // 1.7x on the 128-plane 15x15 case).  Every (group, tile) pair flushes its tile once, so it
-    // only pays when there are enough visibilities per pair to amortise that.
+    // only pays when there are enough visibilities per pair to amortise that: the number of groups follows the work per
+    // tile, in visibilities of 15 x 15 taps (measured on the 4096^2 / 128-plane shape, tools/r3_wg_sweep.sh and
+    // profiles/r03_wgroups_by_size.txt: 1.5 x 10^6 visibilities are fastest with 1 group, 3 x 10^6 with 2, 6 - 25 x 10^6
+    // with 4 - by 24 %, 17 %, 5 % over 8 - from 5 x 10^7 on with 8; 7 x 7 kernels need 4.6 times the visibilities)
     int ng = (int)ctx->opt.wgroups;
     if (ng == 0) {
-        ng = (W >= 8 && n / ((int64_t)g->ntiles * 8) >= 256) ? 8 : 1;
+        ng = auto_groups(g->ntiles);
         // very large grids: the pre-pass counts the bins in LDS-histogram windows; each window after the first
         // re-reads the 8-byte pre-records (0.2 ms per 10^8).  Up to four windows 8 groups still win
         // (8192^2, 1.25 x 10^8 visibilities: 21.2 ms against 21.9 with 4 groups, 25.5 with 16)
@@ -441,6 +456,14 @@ int gridhip_get_option(gridhip_ctx *ctx, const char *key, int64_t *value)
         GH_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         *value = h;
         return GRIDHIP_OK;
+    }
+    {
+        static const char *const names[4] = {"last_wgroups", "last_tile_x", "last_tile_y", "last_bigtile"};
+        for (int i = 0; i < 4; ++i)
+            if (!strcmp(key, names[i])) {
+                *value = ctx->last_geom[i];
+                return GRIDHIP_OK;
+            }
     }
     if (!strcmp(key, "last_path")) {
         *value = ctx->last_path;

@@ -6,10 +6,14 @@ from the oracle's, so results are a tolerance, never bit-exact; observed error i
 Integer work (cell / sub-cell indices) must match exactly — it shows up as O(1) grid errors
 when it does not.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TOL = 1e-10
 
@@ -814,6 +818,27 @@ def test_reserved_cus_do_not_change_the_grid(ctx, oracle):
     finally:
         ctx.set_option("reserve_cus", 0)
         ctx.set_option("sort", 0)
+
+
+@pytest.mark.parametrize("n,groups", [(1_500_000, 1), (3_000_000, 2), (12_500_000, 4), (60_000_000, 8)])
+def test_automatic_w_groups_follow_the_work_per_tile(ctx, n, groups):
+    """The number of w-groups a call gets when option "wgroups" does not say follows the work per tile (ctx.hip,
+    profiles/r03_wgroups_by_size.txt: at 6 - 25 x 10^6 visibilities on the headline shape four groups beat eight by 5 - 24 %,
+    below that two and one do): read-only option "last_wgroups" shows the choice; the grid's checksum is right with
+    every one of them."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    _, N, W, Q, S = bench.WORKLOADS["cfg3"]
+    dev = torch.device("cuda:0")
+    gcf = bench.synth_kernels(W, Q, S, dev)
+    u, v, wb, vis = bench.synth_vis(n, N, W, S, 77, dev)
+    G = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    ctx.convgrid2(gcf, G, (u, v, None), wb, vis)
+    torch.cuda.synchronize()
+    assert ctx.get_option("last_wgroups") == groups and ctx.get_option("last_path") == 1 and ctx.get_option("errors") == 0
+    expect, scale = bench.expected_checksum(u, v, wb, vis, gcf, N)
+    assert abs(G.sum().item() - expect.item()) / scale.item() < 1e-10
 
 
 @pytest.mark.parametrize("S", [15, 23])
