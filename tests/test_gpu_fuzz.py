@@ -2,6 +2,8 @@
 tuning options; convgrid2 and degrid2 through the C ABI against the CPU oracle (1e-10 relative).
 Catches shape-dependent indexing mistakes (LDS pitch, tile offsets, halo clipping, chunk/batch
 boundaries) that the fixed-shape parity tests could miss."""
+import os
+
 import numpy as np
 import pytest
 
@@ -58,7 +60,12 @@ def make_case(seed, large=False):
     return (H, Wd, gcf, u, v, wb, vis, opts)
 
 
-@pytest.mark.parametrize("seed", list(range(40)) + [f"L{i}" for i in range(24)])
+# GRIDHIP_FUZZ_EXTRA=k adds k more seeds of every kind (a one-off wider run; the committed suite stays at minutes)
+_EXTRA = int(os.environ.get("GRIDHIP_FUZZ_EXTRA", "0"))
+
+
+@pytest.mark.parametrize("seed", list(range(40)) + [f"L{i}" for i in range(24)] + list(range(1000, 1000 + _EXTRA)) +
+                         [f"L{i}" for i in range(100, 100 + _EXTRA)])
 def test_fuzz_convgrid2_and_degrid2(ctx, oracle, seed):
     large = isinstance(seed, str)
     seed = 500 + int(seed[1:]) if large else seed
@@ -88,7 +95,7 @@ def test_fuzz_convgrid2_and_degrid2(ctx, oracle, seed):
         assert rel(dgot, dref) < TOL, (H, Wd, gcf.shape, len(u), opts)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", list(range(16)) + list(range(100, 100 + _EXTRA)))
 def test_fuzz_awgrid(ctx, oracle, seed):
     """aw gridders: random supports (compile-time and generic build kernels, tap-reusing and general tile kernels),
     antenna / plane / oversampling counts, repeated and unique keys, the per-key cache on and off, bad indices."""
