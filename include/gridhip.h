@@ -104,9 +104,9 @@ int gridhip_synchronize(gridhip_ctx *ctx);
  *               kernel's work-groups are not persistent - each takes eight work items and leaves, and up to 2 048
  *               further ones are launched to follow them - so a kernel queued on another stream gets a CU within a few
  *               hundred microseconds while nothing idles when none is queued (+0.5 % on the tile kernel instead of
- *               +10 %).  Use multiples of 32 (one CU per shader engine of every XCD): with fewer the dispatcher's
- *               rotation over the shader engines stops at one without a free CU and the rest of the k stay idle
- *               (profiles/r03_yield_cus.txt)
+ *               +10 %).  k is rounded up to a multiple of 32 (one CU per shader engine of every XCD): with fewer the
+ *               dispatcher's rotation over the shader engines stops at one without a free CU and the CUs given up stay
+ *               idle (profiles/r03_yield_cus.txt)
  *   "bigtile"   the tap-reusing kernel's tile uses all of the LDS (65 x 110 cells at 15 x 15 instead of 65 x 89): a
  *               quarter more visibilities per kernel slice and work item, for an address add per tap step; pays
  *               where items are sparse (fewer than two visibilities per slice and item), not where the LDS atomic
