@@ -483,29 +483,6 @@ __global__ void __launch_bounds__(1024) bin_scatter_kernel(Geom g, int64_t n, co
 // hand LDS data to each other; registers fed by global loads and returning atomics are waited for where they are used.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The slot of this lane's record among the records of its key in the LDS histogram `hist` (key < 0: none, returns 0).
-// Neighbouring lanes hold neighbouring records of the stream, and real streams come in runs - the channels of one
-// baseline and time fall into the same bin - so a run of equal keys in neighbouring lanes is reserved by its first lane
-// with ONE atomic and the others take their place behind it: 64 returning atomics on one LDS address serialise (a
-// stream of 64-sample tracks took the two scatter levels from 0.36 + 0.47 to 0.54 + 0.65 ms).  On a random stream every
-// lane is the head of its own run: the same atomics as before plus a dozen integer instructions.
-__device__ __forceinline__ int run_rank(int32_t *hist, int key)
-{
-    const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(key, 1);
-    const bool valid = key >= 0, head = valid && (lane == 0 || prev != key);
-    const unsigned long long hm = __ballot(head), vm = __ballot(valid);
-    const unsigned long long upto = (2ull << lane) - 1;            // lanes 0 .. lane (lane 63: all)
-    const unsigned long long below = hm & upto;                    // a valid lane has its run's head at or below it
-    const int hl = valid && below ? 63 - __clzll((long long)below) : lane;
-    const unsigned long long stops = (hm | ~vm) & ~upto;           // where the run ends: the next head, or the next lane without a key
-    const int end = stops ? __ffsll((long long)stops) - 1 : 64;
-    int base = 0;
-    if (head) base = atomicAdd(&hist[key], end - lane);
-    base = __shfl(base, hl);
-    return valid ? base + (lane - hl) : 0;
-}
-
 template <int NT, typename F>
 __device__ __forceinline__ void scan_entries(int32_t *hist, int nent, int32_t *wtot, int (&res)[1024 / NT], F &&reserve)
 {
