@@ -31,7 +31,8 @@
  *                     `grid` and `vis_out` must be ordinary device allocations (hipMalloc: coarse-grained
  *                     memory): the tile kernels flush with hardware fp64 atomics (global_atomic_add_f64),
  *                     which fine-grained / host-coherent mappings do not support.
- * A context is bound to one device and one stream and is not thread-safe.
+ * A context is bound to one device and one stream and is not thread-safe; contexts are independent of each other (one
+ * per host thread: tests/test_gpu_limits.py runs two on one GPU concurrently).
  */
 #ifndef GRIDHIP_H
 #define GRIDHIP_H
