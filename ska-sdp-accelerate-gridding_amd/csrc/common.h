@@ -163,6 +163,15 @@ struct gridhip_ctx {
     // context's work is ordered on one stream (gridhip_set_stream orders a new one after the old), so a block handed
     // back by one call may be handed out to the next without waiting.
     std::vector<std::pair<void *, size_t>> pool_free;
+    // the last w-kernel table w_cache_imaging built (imaging.hip): the table depends on the field of view, the w-planes
+    // and the kernel's shape only, and an imaging run calls with the same ones again and again (image and PSF, every
+    // major cycle) - a call whose planes match takes the table as it is (21 planes: 1.6 ms of small kernels saved)
+    struct {
+        double theta = 0.0;
+        int64_t wstep = 0, wmin = 0, nplanes = 0, npixFF = 0, S = 0, Q = 0;
+        void *ptr = nullptr;
+        size_t bytes = 0;
+    } wk_cache;
     // which gridder the last convgrid / convgrid2 / degrid2 / plan call used (read-only option "last_path"):
     // 1 = tap-reusing tile kernel, 2 = the same through sub-footprints (one record per spatial part of the kernel),
     // 3 = general tile kernel (small problems; shapes or sizes the tap-reusing kernel does not take),

@@ -201,14 +201,20 @@ __global__ void fill_ones_kernel(int64_t n, double2 *__restrict__ a)
 
 // w_kernel far field, padded (src/Gridding.hs:610-667, pad_mid :682-691 via padder :863-877).
 // padder reads `array ! index2 oldx oldy`: the far field is transposed while it is padded.
-__global__ void wkern_farfield_kernel(int64_t n, int64_t na, double theta, double w, double2 *__restrict__ out)
+// `s`: the output is the padded far field rolled by s both ways (out[y][x] = field[(y+s) mod na][(x+s) mod na]) - the
+// ishift2D the centred transform starts with, written at once instead of by a pass of its own.
+__global__ void wkern_farfield_kernel(int64_t n, int64_t na, double theta, double w, double2 *__restrict__ out, int64_t s)
 {
     const int64_t p0 = na / 2 - n / 2;
     const double step = 1.0 / (double)n;
     const double start = (double)(-(n / 2)) * step;
     const int64_t cells = na * na;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t y = c / na, x = c - y * na;
+        int64_t y = c / na, x = c - y * na;
+        y += s;
+        x += s;
+        y -= y >= na ? na : 0;
+        x -= x >= na ? na : 0;
         int64_t oldx = x - p0, oldy = y - p0;
         double2 v = make_double2(0.0, 0.0);
         if (n == na) {  // pad_mid returns ff untouched
@@ -232,8 +238,11 @@ __global__ void wkern_farfield_kernel(int64_t n, int64_t na, double theta, doubl
 }
 
 // extract_oversampled, src/Gridding.hs:709-728: K[yf,xf,y,x] = af[c - yf + Q*y, c - xf + Q*x] * Q^2
+// `s`, `scale`: af is the transform's raw output; the cell the reference reads is af[(row+s) mod na][(col+s) mod na] *
+// scale - the shift2D and the 1 / na^2 the centred inverse transform ends with, applied to the Q^2 S^2 cells that are
+// used instead of to all na^2 (same two multiplications in the same order: bit-identical).
 __global__ void wkern_extract_kernel(int64_t na, int64_t Q, int64_t S, const double2 *__restrict__ af,
-                                     double2 *__restrict__ out, int conj)
+                                     double2 *__restrict__ out, int conj, int64_t s, double scale)
 {
     const int64_t c0 = na / 2 - Q * (S / 2);
     const double q2 = (double)(Q * Q);
@@ -245,7 +254,11 @@ __global__ void wkern_extract_kernel(int64_t na, int64_t Q, int64_t S, const dou
         const int64_t y = r % S;
         r /= S;
         const int64_t xf = r % Q, yf = r / Q;
-        const double2 v = af[(c0 - yf + Q * y) * na + (c0 - xf + Q * x)];
+        int64_t row = c0 - yf + Q * y + s, col = c0 - xf + Q * x + s;
+        row -= row >= na ? na : 0;
+        col -= col >= na ? na : 0;
+        double2 v = af[row * na + col];
+        v = make_double2(v.x * scale, v.y * scale);
         out[t] = make_double2(v.x * q2, conj ? -(v.y * q2) : v.y * q2);
     }
 }
@@ -302,7 +315,8 @@ static int load_hipfft(gridhip_ctx *ctx)
 // centred transform (src/Gridding.hs:815-829): shift2D . fft2D mode . ishift2D.
 // accelerate-fft: Forward = exp(-i..) unnormalised, Inverse = exp(+i..) scaled by 1/N^2.
 // `in` is preserved, `tmp` and `out` are N*N scratch/output (out may not alias in).
-int dev_fft2c(gridhip_ctx *ctx, int64_t N, const double2 *in, double2 *out, double2 *tmp, bool inverse)
+// the context's cached N x N Z2Z plan, bound to its stream
+static int fft_plan_for(gridhip_ctx *ctx, int64_t N, void **out_plan)
 {
     GH_CHECK(load_hipfft(ctx));
     if (N > 0x7fffffff) return fail(ctx, GRIDHIP_EUNSUPPORTED, "fft size");
@@ -324,6 +338,14 @@ int dev_fft2c(gridhip_ctx *ctx, int64_t N, const double2 *in, double2 *out, doub
         ctx->fft_next = (slot + 1) % 4;
     }
     if (int rc = g_fft.setstream(plan, ctx->stream)) return fail(ctx, GRIDHIP_EHIP, "hipfftSetStream: %d", rc);
+    *out_plan = plan;
+    return GRIDHIP_OK;
+}
+
+int dev_fft2c(gridhip_ctx *ctx, int64_t N, const double2 *in, double2 *out, double2 *tmp, bool inverse)
+{
+    void *plan = nullptr;
+    GH_CHECK(fft_plan_for(ctx, N, &plan));
     hipLaunchKernelGGL(roll_kernel, grid_for(ctx, N * N), dim3(256), 0, ctx->stream, N, in, tmp, N / 2, 1.0);
     if (int rc = g_fft.exec(plan, tmp, tmp, inverse ? 1 /* HIPFFT_BACKWARD */ : -1 /* HIPFFT_FORWARD */))
         return fail(ctx, GRIDHIP_EHIP, "hipfftExecZ2Z: %d", rc);
@@ -335,6 +357,10 @@ int dev_fft2c(gridhip_ctx *ctx, int64_t N, const double2 *in, double2 *out, doub
 
 void fft_release(gridhip_ctx *ctx)
 {
+    if (ctx->wk_cache.ptr) (void)hipFree(ctx->wk_cache.ptr);
+    ctx->wk_cache.ptr = nullptr;
+    ctx->wk_cache.bytes = 0;
+    ctx->wk_cache.nplanes = 0;
     for (int i = 0; i < 4; ++i) {
         if (ctx->fft_plan[i] && g_fft.h) g_fft.destroy(ctx->fft_plan[i]);
         ctx->fft_plan[i] = nullptr;
@@ -346,11 +372,17 @@ int dev_w_kernel(gridhip_ctx *ctx, double theta, double w, int64_t npixFF, int64
                  bool conj, double2 *pad, double2 *af, double2 *tmp)
 {
     const int64_t na = npixFF * Q;
+    // centred inverse transform = shift2D . ifft2D . ishift2D (dev_fft2c); its two rolls are folded into the far-field
+    // kernel's stores and the extraction's loads: three passes over na^2 cells fewer per plane
+    (void)af;
+    (void)tmp;
+    void *plan = nullptr;
+    GH_CHECK(fft_plan_for(ctx, na, &plan));
     hipLaunchKernelGGL(wkern_farfield_kernel, grid_for(ctx, na * na), dim3(256), 0, ctx->stream, npixFF, na, theta, w,
-                       pad);
-    GH_CHECK(dev_fft2c(ctx, na, pad, af, tmp, true));
-    hipLaunchKernelGGL(wkern_extract_kernel, grid_for(ctx, Q * Q * S * S), dim3(256), 0, ctx->stream, na, Q, S, af,
-                       out, conj ? 1 : 0);
+                       pad, na / 2);
+    if (int rc = g_fft.exec(plan, pad, pad, 1 /* HIPFFT_BACKWARD */)) return fail(ctx, GRIDHIP_EHIP, "hipfftExecZ2Z: %d", rc);
+    hipLaunchKernelGGL(wkern_extract_kernel, grid_for(ctx, Q * Q * S * S), dim3(256), 0, ctx->stream, na, Q, S, pad,
+                       out, conj ? 1 : 0, (na + 1) / 2, 1.0 / ((double)na * (double)na));
     GH_CHECK_HIP(ctx, hipGetLastError());
     return GRIDHIP_OK;
 }
@@ -577,7 +609,8 @@ static int build_wkernels(gridhip_ctx *ctx, double theta, int64_t wstep, int64_t
 // same baselines (image and PSF, :538,541); the reference rebuilds everything both times ("no cache
 // despite the name", :405-411) — here the second call reuses it.
 struct WCache {
-    DevBuf pu, pv, wb, table;
+    DevBuf pu, pv, wb;
+    double2 *table = nullptr;  // the context's cached table (gridhip_ctx::wk_cache): not owned
     int64_t nplanes = 0;
     bool ready = false;
     gridhip_plan *plan = nullptr;  // the baselines binned once for both passes
@@ -601,8 +634,35 @@ static int w_cache_prepare(gridhip_ctx *ctx, WCache &c, double theta, int64_t la
     c.ready = true;
     if (n == 0 || c.nplanes == 0) return GRIDHIP_OK;
     if (c.nplanes > 65536) return fail(ctx, GRIDHIP_EUNSUPPORTED, "%lld w-planes", (long long)c.nplanes);
-    GH_CHECK(c.table.alloc(ctx, (size_t)c.nplanes * Q * Q * S * S * 16));
-    return build_wkernels(ctx, theta, wstep, wmin, c.nplanes, npixFF, S, Q, c.table.as<double2>());
+    auto &k = ctx->wk_cache;
+    const size_t bytes = (size_t)c.nplanes * Q * Q * S * S * 16;
+    if (!(k.ptr && k.theta == theta && k.wstep == wstep && k.wmin == wmin && k.nplanes == c.nplanes && k.npixFF == npixFF &&
+          k.S == S && k.Q == Q)) {
+        k.nplanes = 0;  // (not valid while it is rebuilt)
+        if (k.bytes < bytes) {
+            if (k.ptr) {
+                GH_CHECK(sync(ctx));  // (the old table may still be read by work queued on the stream)
+                (void)hipFree(k.ptr);
+                k.ptr = nullptr;
+                k.bytes = 0;
+            }
+            if (hipMalloc(&k.ptr, bytes) != hipSuccess) {
+                k.ptr = nullptr;
+                return fail(ctx, GRIDHIP_ENOMEM, "w-kernel table: %zu bytes", bytes);
+            }
+            k.bytes = bytes;
+        }
+        GH_CHECK(build_wkernels(ctx, theta, wstep, wmin, c.nplanes, npixFF, S, Q, (double2 *)k.ptr));
+        k.theta = theta;
+        k.wstep = wstep;
+        k.wmin = wmin;
+        k.nplanes = c.nplanes;
+        k.npixFF = npixFF;
+        k.S = S;
+        k.Q = Q;
+    }
+    c.table = (double2 *)k.ptr;
+    return GRIDHIP_OK;
 }
 
 // u,v,w in wavelengths, grid zeroed N x N
@@ -615,7 +675,7 @@ static int w_cache_grid_dev(gridhip_ctx *ctx, WCache &c, double theta, int64_t l
     if (!c.plan)
         GH_CHECK(gridhip_plan_create_dev(ctx, N, N, n, c.nplanes, Q, S, S, c.pu.as<double>(), c.pv.as<double>(), 1,
                                          c.wb.as<int64_t>(), &c.plan));
-    GH_CHECK(gridhip_plan_grid_dev(c.plan, c.table.as<double>(), vis, grid));
+    GH_CHECK(gridhip_plan_grid_dev(c.plan, (const double *)c.table, vis, grid));
     return sync(ctx);
 }
 
