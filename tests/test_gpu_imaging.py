@@ -171,3 +171,31 @@ def test_w_cache_imaging_resident(ctx):
     got3 = ctx.w_cache_imaging(ko, theta, lam, t(np.stack([u, v, w], 1)), None, t(vis))
     torch.cuda.synchronize()
     assert rel(got.cpu().numpy(), ref) < 1e-13 and rel(got3.cpu().numpy(), ref) < 1e-13
+
+
+def test_w_kernel_table_kept_between_calls_is_never_stale(ctx):
+    """The context keeps the last w-kernel table w_cache_imaging built and reuses it when the field of view, the planes
+    and the kernel's shape match (gridhip_ctx::wk_cache).  Calls that alternate between geometries - another field of
+    view, another w range (other planes), another support, another oversampling - must each come out exactly as a
+    fresh context computes them, and a repeated geometry exactly as the first time."""
+    import gridhip
+    lam = 2560
+    u, v, w, vis = _vis(11, 2500, 1200, 900)
+    cases = [(0.05, dict(wstep=100, qpx=2, npixFF=64, npixKern=15), w),
+             (0.04, dict(wstep=100, qpx=2, npixFF=64, npixKern=15), w),          # another field of view
+             (0.05, dict(wstep=100, qpx=2, npixFF=64, npixKern=15), w * 0.5),    # other planes
+             (0.05, dict(wstep=100, qpx=2, npixFF=64, npixKern=9), w),           # another support
+             (0.05, dict(wstep=100, qpx=4, npixFF=64, npixKern=15), w),          # another oversampling
+             (0.05, dict(wstep=50, qpx=2, npixFF=64, npixKern=15), w)]           # another plane spacing
+    fresh = []
+    for theta, ko, ww in cases:
+        c = gridhip.Context(0)
+        fresh.append(c.w_cache_imaging(ko, theta, lam, (u, v, ww), None, vis))
+        c.close()
+    order = [0, 0, 1, 0, 2, 2, 3, 4, 5, 0, 5, 1]
+    for k in order:
+        theta, ko, ww = cases[k]
+        got = ctx.w_cache_imaging(ko, theta, lam, (u, v, ww), None, vis)
+        assert np.array_equal(got, fresh[k]) or rel(got, fresh[k]) < 1e-13, k
+    ref, _, _ = P.w_cache_imaging(cases[2][0], lam, u, v, cases[2][2], vis, 100, 2, 64, 15)
+    assert rel(fresh[2], ref) < TOL
