@@ -134,20 +134,25 @@ __global__ void weight_apply_kernel(int64_t N, int64_t n, const double *__restri
     }
 }
 
-// make_grid_hermitian, src/Gridding.hs:585-605 (out of place)
-__global__ void hermitian_kernel(int64_t N, const double2 *__restrict__ in, double2 *__restrict__ out)
+// make_grid_hermitian, src/Gridding.hs:585-605 (out of place).  `s`: the output is the Hermitian grid rolled by s both
+// ways (out[y][x] = H[(y+s) mod N][(x+s) mod N]) - the ishift2D the centred transform starts with, written at once.
+__global__ void hermitian_kernel(int64_t N, const double2 *__restrict__ in, double2 *__restrict__ out, int64_t s)
 {
     const bool even = (N % 2) == 0;
     const int64_t cells = N * N;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t y = c / N, x = c - y * N;
+        int64_t y = c / N, x = c - y * N;
+        y += s;
+        x += s;
+        y -= y >= N ? N : 0;
+        x -= x >= N ? N : 0;
         double2 a = make_double2(0.0, 0.0);
         if (even) {
             if (x != 0 && y != 0) a = in[(N - y) * N + (N - x)];
         } else {
             a = in[(N - 1 - y) * N + (N - 1 - x)];
         }
-        const double2 g = in[c];
+        const double2 g = in[y * N + x];
         out[c] = make_double2(g.x + a.x, g.y - a.y);
     }
 }
@@ -167,12 +172,24 @@ __global__ void roll_kernel(int64_t N, const double2 *__restrict__ in, double2 *
     }
 }
 
+// N > 0: `in` is a transform's raw N x N output and the cell read for c = (y, x) is in[(y+s) mod N][(x+s) mod N] * scale -
+// the shift2D and the 1 / N^2 the centred inverse transform ends with, applied while the real part is taken instead
+// of in a pass of their own (the same multiplication: bit-identical).
 __global__ void real_max_kernel(int64_t cells, const double2 *__restrict__ in, double *__restrict__ real_out,
-                                unsigned long long *__restrict__ maxbits)
+                                unsigned long long *__restrict__ maxbits, int64_t N, int64_t s, double scale)
 {
     double m = -INFINITY;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (int64_t)gridDim.x * blockDim.x) {
-        const double r = in[c].x;
+        double r;
+        if (N > 0) {
+            int64_t y = c / N, x = c - y * N;
+            y += s;
+            x += s;
+            y -= y >= N ? N : 0;
+            x -= x >= N ? N : 0;
+            r = in[y * N + x].x * scale;
+        } else
+            r = in[c].x;
         if (real_out) real_out[c] = r;
         m = r > m ? r : m;
     }
@@ -180,7 +197,14 @@ __global__ void real_max_kernel(int64_t cells, const double2 *__restrict__ in, d
         const double o = __shfl_xor(m, off, 64);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0 && maxbits) {
+    // one atomic per work-group (one per wave was 1.6 x 10^4 serialised 64-bit atomics on one address: most of this
+    // kernel's 0.11 ms at 2400^2 cells)
+    __shared__ double sm[16];
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) sm[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0 && maxbits) {
+        for (int i = 1; i < nw; ++i) m = sm[i] > m ? sm[i] : m;
         // order-preserving map of doubles onto unsigned integers so atomicMax works
         unsigned long long b = (unsigned long long)__double_as_longlong(m);
         b = (b & 0x8000000000000000ULL) ? ~b : (b | 0x8000000000000000ULL);
@@ -574,13 +598,18 @@ static int do_imaging_impl(gridhip_ctx *ctx, double theta, int64_t lam, int64_t 
         GH_CHECK_HIP(ctx, hipMemsetAsync(dg.p, 0, cells * 16, ctx->stream));
         GH_CHECK(imgfn(N, du.as<double>(), dv.as<double>(), dw.as<double>(),
                        pass == 0 ? dvis.as<double>() : dwt.as<double>(), dg.as<double>()));
+        // centred inverse transform (shift2D . ifft2D . ishift2D, dev_fft2c) with its two rolls folded into the Hermitian
+        // fill's stores and the real part's loads: four passes over the N^2 grid fewer per call
+        void *plan = nullptr;
+        GH_CHECK(fft_plan_for(ctx, N, &plan));
         hipLaunchKernelGGL(hermitian_kernel, grid_for(ctx, cells), dim3(256), 0, ctx->stream, N, dg.as<double2>(),
-                           dh.as<double2>());
-        GH_CHECK(dev_fft2c(ctx, N, dh.as<double2>(), dg.as<double2>(), dtmp.as<double2>(), true));
+                           dh.as<double2>(), N / 2);
+        if (int rc = g_fft.exec(plan, dh.p, dh.p, 1 /* HIPFFT_BACKWARD */)) return fail(ctx, GRIDHIP_EHIP, "hipfftExecZ2Z: %d", rc);
         if (pass == 1) GH_CHECK(h2d(ctx, dmax.p, &neg_inf_bits, 8));
         hipLaunchKernelGGL(real_max_kernel, grid_for(ctx, cells), dim3(256), 0, ctx->stream, (int64_t)cells,
-                           dg.as<double2>(), pass == 0 ? dreal.as<double>() : dtmp.as<double>(),
-                           pass == 1 ? dmax.as<unsigned long long>() : (unsigned long long *)nullptr);
+                           dh.as<double2>(), pass == 0 ? dreal.as<double>() : dtmp.as<double>(),
+                           pass == 1 ? dmax.as<unsigned long long>() : (unsigned long long *)nullptr, N, (N + 1) / 2,
+                           1.0 / ((double)N * (double)N));
     }
     // normalise both by max(psf) (:544-548); dtmp holds the real PSF, dreal the real image
     hipLaunchKernelGGL(divide_kernel, grid_for(ctx, cells), dim3(256), 0, ctx->stream, (int64_t)cells,
@@ -804,7 +833,7 @@ int gridhip_make_grid_hermitian(gridhip_ctx *ctx, int64_t N, double *grid)
     GH_CHECK(b.alloc(ctx, cells * 16));
     GH_CHECK(h2d(ctx, a.p, grid, cells * 16));
     hipLaunchKernelGGL(hermitian_kernel, grid_for(ctx, cells), dim3(256), 0, ctx->stream, N, a.as<double2>(),
-                       b.as<double2>());
+                       b.as<double2>(), (int64_t)0);
     GH_CHECK_HIP(ctx, hipGetLastError());
     GH_CHECK(d2h(ctx, grid, b.p, cells * 16));
     return sync(ctx);
