@@ -289,6 +289,9 @@ struct Tables {
     int32_t *scalars;     // = ctx->d_scalars
 };
 void fft_release(gridhip_ctx *ctx);
+// a plan whose records live in the context's own scratch (plan.hip): for callers that keep it for one call's passes
+int plan_create_borrowed(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, int64_t W, int64_t Q, int64_t gh, int64_t gw,
+                         const double *u, const double *v, int64_t uv_stride, const int64_t *wbin, gridhip_plan **out);
 Tables tables_of(gridhip_ctx *ctx, const Geom &g);
 size_t tables_bytes(const Geom &g);
 

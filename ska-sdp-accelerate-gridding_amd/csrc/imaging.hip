@@ -606,7 +606,7 @@ static int do_imaging_impl(gridhip_ctx *ctx, double theta, int64_t lam, int64_t 
                            dh.as<double2>(), N / 2);
         if (int rc = g_fft.exec(plan, dh.p, dh.p, 1 /* HIPFFT_BACKWARD */)) return fail(ctx, GRIDHIP_EHIP, "hipfftExecZ2Z: %d", rc);
         if (pass == 1) GH_CHECK(h2d(ctx, dmax.p, &neg_inf_bits, 8));
-        hipLaunchKernelGGL(real_max_kernel, grid_for(ctx, cells), dim3(256), 0, ctx->stream, (int64_t)cells,
+        hipLaunchKernelGGL(real_max_kernel, dim3((unsigned)ctx->num_cu * 4), dim3(256), 0, ctx->stream, (int64_t)cells,
                            dh.as<double2>(), pass == 0 ? dreal.as<double>() : dtmp.as<double>(),
                            pass == 1 ? dmax.as<unsigned long long>() : (unsigned long long *)nullptr, N, (N + 1) / 2,
                            1.0 / ((double)N * (double)N));
@@ -715,8 +715,8 @@ static int w_cache_grid_dev(gridhip_ctx *ctx, WCache &c, double theta, int64_t l
     if (!c.ready) GH_CHECK(w_cache_prepare(ctx, c, theta, lam, wstep, Q, npixFF, S, n, u, v, w));
     if (n == 0 || c.nplanes == 0) return GRIDHIP_OK;
     if (!c.plan)
-        GH_CHECK(gridhip_plan_create_dev(ctx, N, N, n, c.nplanes, Q, S, S, c.pu.as<double>(), c.pv.as<double>(), 1,
-                                         c.wb.as<int64_t>(), &c.plan));
+        GH_CHECK(plan_create_borrowed(ctx, N, N, n, c.nplanes, Q, S, S, c.pu.as<double>(), c.pv.as<double>(), 1,
+                                      c.wb.as<int64_t>(), &c.plan));  // (nothing else grids on this context before both passes are done)
     GH_CHECK(gridhip_plan_grid_dev(c.plan, (const double *)c.table, vis, grid));
     return sync(ctx);
 }

@@ -15,6 +15,10 @@ struct gridhip_plan {
     gridhip::Workspace recs, tables;
     int64_t n = 0;
     bool all_binned = false;  // no visibility was dropped: degrid writes every element of its output
+    // the records live in the context's own scratch instead of the plan's (imaging.hip: a plan that lasts for the two
+    // passes of one call - no hipMalloc, no hipFree with its device-wide synchronisation); valid until the context's
+    // next gridding call that is not this plan's
+    bool borrowed = false;
 };
 
 using namespace gridhip;
@@ -25,22 +29,45 @@ struct Lend {
     gridhip_plan *p;
     explicit Lend(gridhip_plan *pl) : p(pl)
     {
+        if (p->borrowed) return;
         std::swap(p->ctx->recs, p->recs);
         std::swap(p->ctx->tables, p->tables);
     }
     ~Lend()
     {
+        if (p->borrowed) return;
         std::swap(p->ctx->recs, p->recs);
         std::swap(p->ctx->tables, p->tables);
     }
 };
 }  // namespace
 
+static int plan_create(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, int64_t W, int64_t Q, int64_t gh, int64_t gw,
+                       const double *u, const double *v, int64_t uv_stride, const int64_t *wbin, gridhip_plan **out,
+                       bool borrowed);
+
+namespace gridhip {
+int plan_create_borrowed(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, int64_t W, int64_t Q, int64_t gh, int64_t gw,
+                         const double *u, const double *v, int64_t uv_stride, const int64_t *wbin, gridhip_plan **out)
+{
+    return plan_create(ctx, H, Wd, n, W, Q, gh, gw, u, v, uv_stride, wbin, out, true);
+}
+}  // namespace gridhip
+
 extern "C" {
 
 int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, int64_t W, int64_t Q, int64_t gh,
                             int64_t gw, const double *u, const double *v, int64_t uv_stride, const int64_t *wbin,
                             gridhip_plan **out)
+{
+    return plan_create(ctx, H, Wd, n, W, Q, gh, gw, u, v, uv_stride, wbin, out, false);
+}
+
+}  // extern "C"
+
+static int plan_create(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, int64_t W, int64_t Q, int64_t gh, int64_t gw,
+                       const double *u, const double *v, int64_t uv_stride, const int64_t *wbin, gridhip_plan **out,
+                       bool borrowed)
 {
     if (!ctx || !out) return GRIDHIP_EINVAL;
     *out = nullptr;
@@ -53,6 +80,7 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
     if (!p) return GRIDHIP_ENOMEM;
     p->ctx = ctx;
     p->n = n;
+    p->borrowed = borrowed;
     int rc = prepare(ctx, H, Wd, W, Q, gh, gw, n, &p->p);
     if (rc == GRIDHIP_OK && p->p.direct) rc = fail(ctx, GRIDHIP_EUNSUPPORTED, "plan: support too large for an LDS tile");
     if (rc == GRIDHIP_OK && !rec_fits(p->p.g)) rc = fail(ctx, GRIDHIP_EUNSUPPORTED, "plan: slices x visibilities above 2^50");
@@ -82,9 +110,15 @@ int gridhip_plan_create_dev(gridhip_ctx *ctx, int64_t H, int64_t Wd, int64_t n, 
     return GRIDHIP_OK;
 }
 
+extern "C" {
+
 int gridhip_plan_destroy(gridhip_plan *p)
 {
     if (!p) return GRIDHIP_OK;
+    if (p->borrowed) {  // (nothing of its own on the device)
+        delete p;
+        return GRIDHIP_OK;
+    }
     (void)hipSetDevice(p->ctx->device);
     (void)hipDeviceSynchronize();
     if (p->recs.ptr) (void)hipFree(p->recs.ptr);
